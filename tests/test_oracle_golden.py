@@ -1,0 +1,116 @@
+"""Pins oracle/ (our CPU restatement) to outputs of the reference itself (tests/golden, made by
+tools/make_goldens.py from /root/reference).  CPU only."""
+import numpy as np
+import pytest
+
+from yue_amd import synth
+from util import csr_from_events, gj, gz, mask_rows, rel_err, sha
+
+CASES = ['c1_k10_e1', 'c1_k10_e5', 'd2_k64_e1', 'd3_k128_e2']
+
+
+def _case(tag):
+    z, meta = gz('g4_%s.npz' % tag), gj('g4_%s.json' % tag)
+    iters = int(z['iters'])
+    E = len(z['u']) // iters
+    return z, meta, iters, E
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_python_sampler_replica_is_bit_exact(orc, tag):
+    # recommender/cf/BPR.py:46-48 driven by random.seed(seed): every raw draw and every accepted j
+    z, _, iters, E = _case(tag)
+    m, n = int(z['m']), int(z['n'])
+    indptr, indices = csr_from_events(z['u'][:E], z['i'][:E], m)
+    j, draws = orc.sample_python(int(z['seed']), iters, z['u'][:E], n, indptr, indices, want_draws=True)
+    assert np.array_equal(draws, z['draws'])
+    assert np.array_equal(j, z['j'])
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_sequential_epochs_match_reference(orc, tag):
+    # BPR.py:40-62 + IterativeRecommender.py:47-75: factors within 1e-5 rel, printed lines identical
+    z, meta, iters, E = _case(tag)
+    m, n, k, seed = int(z['m']), int(z['n']), int(z['k']), int(z['seed'])
+    P, Q = synth.init_factors(m, n, k, seed)
+    assert sha(P) == meta['P0_sha256'] and sha(Q) == meta['Q0_sha256']
+    lr, last = 0.02, 0.0
+    for ep in range(iters):
+        sl = slice(ep * E, (ep + 1) * E)
+        nll = orc.bpr_sequential(P, Q, z['u'][sl], z['i'][sl], z['j'][sl], lr, 0.01, 0.01)
+        # BPR.py:59 under NumPy 2 promotion: python-float * float32 -> float32, loss becomes float32
+        reg = np.float32(0.01) * np.float32(orc.sumsq(P)) + np.float32(0.01) * np.float32(orc.sumsq(Q))
+        loss = np.float32(nll) + reg
+        line = 'BPR [1] iteration %d: loss = %.4f, delta_loss = %.5f learning_Rate = %.5f' % (ep + 1, loss, last - loss, lr)
+        assert line == meta['lines'][ep]
+        if not abs(last - loss) < 1e-3:
+            if ep + 1 > 1:
+                lr = lr * 1.01 if abs(last) > abs(loss) else lr * 0.5
+            lr = min(lr, 1.0)
+        last = loss
+    assert rel_err(P, z['P']) < 1e-5 and rel_err(Q, z['Q']) < 1e-5
+    assert abs(float(last) - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
+    assert abs(lr - float(z['lRate'])) < 1e-12
+
+
+@pytest.mark.parametrize('tag,N', [('c1_top10', 10), ('c1_top20', 20)])
+def test_overwrite_scan_lists_match_reference(orc, tag, N):
+    # IterativeRecommender.py:93-145 on the reference's own trained factors: integer lists identical
+    z = gz('g4_c1_k10_e1.npz')
+    ev = gz('g2_events_c1.npz')
+    g = gz('g5_%s.npz' % tag)
+    indptr, indices = csr_from_events(ev['ev_u'], ev['ev_i'], int(z['m']))
+    users = g['test_users']
+    mp, mi = mask_rows(indptr, indices, users)
+    ids, sc, rc = orc.topn_scan(z['P'], z['Q'], users, N, mp, mi)
+    assert rc == 0
+    assert np.array_equal(ids, g['rec_ids'])
+    # F4: it is not a top-N -- slot 0 is the maximum, the rest is order dependent
+    tid, tsc, _ = orc.topn_true(z['P'], z['Q'], users, N, mp, mi)
+    assert np.array_equal(ids[:, 0], tid[:, 0])
+    assert (ids != tid).any()
+    for t in range(16):
+        s = orc.scores(z['P'], z['Q'], int(users[t]))
+        assert np.abs(s - g['predict16'][t]).max() <= 4e-7 * np.abs(g['predict16'][t]).max()
+
+
+def test_scan_too_few_candidates_flags(orc):
+    # IterativeRecommender.py:126 raises IndexError when fewer than N candidates remain
+    rs = np.random.RandomState(0)
+    P = rs.rand(2, 4).astype(np.float32)
+    Q = rs.rand(6, 4).astype(np.float32)
+    mp = np.array([0, 3, 3], np.int64)
+    mi = np.array([0, 2, 4], np.int32)
+    ids, sc, rc = orc.topn_scan(P, Q, np.array([0, 1], np.int32), 5, mp, mi)
+    assert rc == -1
+    assert set(ids[1].tolist()) <= set(range(6)) and (ids[0][3:] == -1).all()
+
+
+def test_rounds_of_one_equal_sequential(orc):
+    z, _, _, E = _case('d2_k64_e1')
+    m, n, k = int(z['m']), int(z['n']), int(z['k'])
+    P1, Q1 = synth.init_factors(m, n, k, 7)
+    P2, Q2 = P1.copy(), Q1.copy()
+    T = 2000
+    a = orc.bpr_sequential(P1, Q1, z['u'][:T], z['i'][:T], z['j'][:T], 0.02, 0.01, 0.01)
+    b = orc.bpr_rounds(P2, Q2, z['u'][:T], z['i'][:T], z['j'][:T], np.arange(T + 1), 0.02, 0.01, 0.01)
+    assert rel_err(P2, P1) < 2e-6 and rel_err(Q2, Q1) < 2e-6
+    assert abs(a - b) < 1e-9 * abs(a)
+
+
+def test_counter_sampler_properties(orc):
+    ev = gz('g2_events_c1.npz')
+    m, n = 1000, 1000
+    indptr, indices = csr_from_events(ev['ev_u'], ev['ev_i'], m)
+    j0 = orc.sample_counter(123, 0, ev['ev_u'], n, indptr, indices)
+    j1 = orc.sample_counter(123, 1, ev['ev_u'], n, indptr, indices)
+    assert (j0 >= 0).all() and (j0 < n).all() and (j0 != j1).mean() > 0.9
+    for e in range(0, len(j0), 97):
+        u = ev['ev_u'][e]
+        assert j0[e] not in set(indices[indptr[u]:indptr[u + 1]].tolist())
+    # an offset slice draws the same values as the full call (event index is the counter)
+    part = orc.sample_counter(123, 0, ev['ev_u'][500:900], n, indptr, indices, e0=500)
+    assert np.array_equal(part, j0[500:900])
+    # roughly uniform over the non-listened items
+    hist = np.bincount(j0, minlength=n)
+    assert hist.max() < 60

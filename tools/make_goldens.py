@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE (0411tony/Yue at /root/reference).
+
+Only runs where /root/reference exists (the build container).  Nothing from the
+reference is copied: the fixtures are inputs (seeds, our synthetic log) and the
+outputs the reference computes from them.
+
+How the reference is driven:
+  * recommender/cf/BPR.py imports tensorflow at module top for its *live* Adam path;
+    the NumPy SGD loop we pin is a string literal in the class body
+    (recommender/cf/BPR.py:30-63).  An empty module object named ``tensorflow``
+    satisfies the import; no TF symbol is touched by the NumPy loop.
+  * the loop text is taken from the reference file at run time, dedented and
+    exec'd against a real BPR instance; ``choice`` is wrapped to log every draw.
+  * NumPy and ``random`` are seeded by this harness (the reference seeds neither).
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import tempfile
+import textwrap
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+_tf = types.ModuleType('tensorflow')
+_tf.set_random_seed = lambda s: None
+sys.modules['tensorflow'] = _tf
+
+from tool.config import Config, LineConfig          # noqa: E402  (reference)
+from tool.file import FileIO                         # noqa: E402
+from tool.qmath import sigmoid                       # noqa: E402
+from evaluation.measure import Measure               # noqa: E402
+from recommender.cf.BPR import BPR                   # noqa: E402
+from collections import defaultdict                  # noqa: E402
+from math import log                                 # noqa: E402
+
+from yue_amd import synth                            # noqa: E402  (ours: data generator only)
+
+DEAD_LOOP = textwrap.dedent(open(os.path.join(REF, 'recommender/cf/BPR.py')).read().split("'''")[1])
+
+
+def quiet(fn, *a, **kw):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        r = fn(*a, **kw)
+    return r, buf.getvalue()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_conf(tmp, log_path, k, max_iter, topn='5,10'):
+    """BPR.conf with only record / num.factors / num.max.iter / topN / output dir changed."""
+    lines = open(os.path.join(REF, 'config/BPR.conf')).read().splitlines()
+    out = []
+    for ln in lines:
+        key = ln.split('=')[0]
+        if key == 'record':
+            ln = 'record=' + log_path
+        elif key == 'num.factors':
+            ln = 'num.factors=%d' % k
+        elif key == 'num.max.iter':
+            ln = 'num.max.iter=%d' % max_iter
+        elif key == 'item.ranking':
+            ln = 'item.ranking=-topN ' + topn
+        elif key == 'output.setup':
+            ln = 'output.setup=on -dir ' + os.path.join(tmp, 'results') + '/'
+        out.append(ln)
+    p = os.path.join(tmp, 'BPR_k%d_it%d_%s.conf' % (k, max_iter, topn.replace(',', '_')))
+    open(p, 'w').write('\n'.join(out))
+    return p
+
+
+def load_train(conf):
+    setup = LineConfig(conf['record.setup'])
+    cols = {}
+    for col in setup['-columns'].split(','):
+        a, b = col.split(':')
+        cols[a] = int(b)
+    data, _ = quiet(FileIO.loadDataSet, conf['record'], columns=cols, delim=setup['-delim'])
+    return data
+
+
+def build(conf_path, seed):
+    conf = Config(conf_path)
+    train = load_train(conf)
+    rec, _ = quiet(BPR, conf, train, [])
+    rec.readConfiguration()
+    random.seed(seed)
+    np.random.seed(seed)
+    rec.initModel()
+    return rec
+
+
+def run_dead_loop(rec):
+    """Run the reference's NumPy epoch loop; returns (draw log, stdout)."""
+    draws = []
+
+    def logged_choice(seq):
+        x = random.choice(seq)
+        draws.append(x)
+        return x
+    g = {'defaultdict': defaultdict, 'choice': logged_choice, 'sigmoid': sigmoid, 'log': log, 'np': np}
+    exec(DEAD_LOOP, g)
+    _, out = quiet(g['buildModel'], rec)
+    return draws, out
+
+
+def record_arrays(rec):
+    d = rec.data
+    rt = rec.recType
+    ev_u, ev_i = [], []
+    for user in d.userRecord:
+        for ev in d.userRecord[user]:
+            ev_u.append(d.getId(user, 'user'))
+            ev_i.append(d.getId(ev[rt], rt))
+    return np.array(ev_u, np.int32), np.array(ev_i, np.int32)
+
+
+def triplets_from_draws(rec, draws):
+    """Re-associate logged draws with events: the accepted draw is the first one not listened."""
+    d = rec.data
+    rt = rec.recType
+    listened = defaultdict(set)
+    for user in d.userRecord:
+        for ev in d.userRecord[user]:
+            listened[user].add(ev[rt])
+    it = iter(draws)
+    U, I, J = [], [], []
+    for _ep in range(10 ** 9):
+        try:
+            for user in d.userRecord:
+                for ev in d.userRecord[user]:
+                    j = next(it)
+                    while j in listened[user]:
+                        j = next(it)
+                    U.append(d.getId(user, 'user'))
+                    I.append(d.getId(ev[rt], rt))
+                    J.append(d.getId(j, rt))
+        except StopIteration:
+            break
+    return np.array(U, np.int32), np.array(I, np.int32), np.array(J, np.int32)
+
+
+def g1_config():
+    conf = Config(os.path.join(REF, 'config/BPR.conf'))
+    cases = ['-columns user:1,track:2,artist:3,time:0 -delim ,',
+             '-target track -byTime 0.2',
+             '-target track -byTime 0.2 -sample',
+             '-topN 5,10',
+             '-init 0.02 -max 1',
+             '-init -0.5 -max 1',
+             '-u 0.01 -i 0.01 -b 0.2 -s 0.2',
+             'on -dir ./results/',
+             'off -dir ./results/ -x 1 2 3',
+             '-cv 5 -p',
+             '  -testSet ./dataset/test.txt  ',
+             '-a -1 -b']
+    lc = []
+    for c in cases:
+        x = LineConfig(c)
+        lc.append({'line': c, 'main': x.isMainOn(), 'options': x.options})
+    json.dump({'bpr_conf': conf.config, 'lineconfig': lc}, open(os.path.join(OUT, 'g1_config.json'), 'w'), indent=1)
+
+
+def g7_measure():
+    origin = {'a': {'t1': 1, 't2': 1, 't3': 1}, 'b': {'t9': 1}, 'c': {'t4': 2, 't5': 1}}
+    res = {'a': ['t1', 't1', 't7', 't3', 't8'], 'b': ['t1', 't2', 't3', 't4', 't5'], 'c': ['t5', 't4', 't4', 't0', 't6']}
+    m, _ = quiet(Measure.rankingMeasure, origin, res, [3, 5], 10)
+    json.dump({'origin': origin, 'res': res, 'N': [3, 5], 'itemCount': 10, 'measure': m},
+              open(os.path.join(OUT, 'g7_measure.json'), 'w'), indent=1)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix='yue_gold_')
+    g1_config()
+    g7_measure()
+
+    datasets = {'c1': (1000, 1000, 20), 'd2': (200, 300, 20), 'd3': (120, 200, 20)}
+    logs = {}
+    for name, (m, n, d) in datasets.items():
+        p = os.path.join(tmp, name + '.txt')
+        synth.write_text_log(p, m, n, d)
+        logs[name] = p
+
+    # ---- G2: Record on the C1 log -------------------------------------------------
+    seed = 20260002
+    rec = build(make_conf(tmp, logs['c1'], 10, 1), seed)
+    d = rec.data
+    ev_u, ev_i = record_arrays(rec)
+    users = [d.id2name['user'][i] for i in range(d.getSize('user'))]
+    items = [d.id2name['track'][i] for i in range(d.getSize('track'))]
+    test_users = list(d.testSet.keys())
+    json.dump({'dataset': datasets['c1'], 'm': d.getSize('user'), 'n': d.getSize('track'),
+               'users': users, 'items': items, 'len_trainingData': len(d.trainingData),
+               'recordCount': d.recordCount,
+               'testSet': [[u, list(d.testSet[u].items())] for u in test_users]},
+              open(os.path.join(OUT, 'g2_record_c1.json'), 'w'))
+    np.savez_compressed(os.path.join(OUT, 'g2_events_c1.npz'), ev_u=ev_u, ev_i=ev_i)
+
+    # ---- G4: epochs of the NumPy loop ---------------------------------------------
+    def epoch_case(tag, log_name, k, iters):
+        rec = build(make_conf(tmp, logs[log_name], k, iters), seed)
+        P0, Q0 = rec.P.copy(), rec.Q.copy()
+        draws, out = run_dead_loop(rec)
+        U, I, J = triplets_from_draws(rec, draws)
+        drawn_ids = np.array([rec.data.getId(x, rec.recType) for x in draws], np.int32)
+        lines = [ln for ln in out.splitlines() if 'iteration' in ln]
+        np.savez_compressed(os.path.join(OUT, 'g4_%s.npz' % tag),
+                            seed=seed, k=k, iters=iters, m=P0.shape[0], n=Q0.shape[0],
+                            u=U, i=I, j=J, draws=drawn_ids,
+                            P=rec.P, Q=rec.Q, loss=np.float64(rec.loss), lastLoss=np.float64(rec.lastLoss),
+                            lRate=np.float64(rec.lRate),
+                            loss_is_f32=isinstance(rec.loss, np.float32))
+        json.dump({'lines': lines, 'P0_sha256': sha(P0), 'Q0_sha256': sha(Q0),
+                   'dataset': datasets[log_name], 'loss_type': type(rec.loss).__name__},
+                  open(os.path.join(OUT, 'g4_%s.json' % tag), 'w'), indent=1)
+        return rec
+
+    rec1 = epoch_case('c1_k10_e1', 'c1', 10, 1)
+    epoch_case('c1_k10_e5', 'c1', 10, 5)
+    epoch_case('d2_k64_e1', 'd2', 64, 1)
+    epoch_case('d3_k128_e2', 'd3', 128, 2)
+
+    # ---- G5/G6: predict + evalRanking + ranking_performance on the trained C1 model ---
+    def ranking_case(tag, topn):
+        rec = build(make_conf(tmp, logs['c1'], 10, 1, topn), seed)
+        run_dead_loop(rec)
+        assert sha(rec.P) == sha(rec1.P) and sha(rec.Q) == sha(rec1.Q)
+        d = rec.data
+        res_dir = os.path.join(tmp, 'results')
+        before = set(os.listdir(res_dir)) if os.path.isdir(res_dir) else set()
+        _, out = quiet(rec.evalRanking)
+        new = sorted(set(os.listdir(res_dir)) - before)
+        lists_txt = [open(os.path.join(res_dir, f)).read() for f in new if 'items' in f][0]
+        # recList is local to evalRanking: recover ids from the lists file is ambiguous (names are
+        # concatenated without separator), so re-run the selection through the same method by
+        # capturing Measure.rankingMeasure's input.
+        captured = {}
+        orig = Measure.rankingMeasure
+
+        def spy(origin, res, N, itemCount):
+            captured['res'] = {u: list(v) for u, v in res.items()}
+            captured['N'] = list(N)
+            captured['itemCount'] = itemCount
+            return orig(origin, res, N, itemCount)
+        Measure.rankingMeasure = staticmethod(spy)
+        try:
+            quiet(rec.evalRanking)
+        finally:
+            Measure.rankingMeasure = staticmethod(orig)
+        tu = list(d.testSet.keys())
+        ids = np.array([[d.getId(x, 'track') for x in captured['res'][u]] for u in tu], np.int32)
+        tuid = np.array([d.getId(u, 'user') for u in tu], np.int32)
+        pred = np.stack([rec.predict(u) for u in tu[:16]])
+        np.savez_compressed(os.path.join(OUT, 'g5_%s.npz' % tag), test_users=tuid, rec_ids=ids,
+                            predict16=pred)
+        json.dump({'topN': topn, 'measure': rec.measure, 'lists_txt': lists_txt,
+                   'itemCount': captured['itemCount']},
+                  open(os.path.join(OUT, 'g5_%s.json' % tag), 'w'))
+        return rec
+
+    recr = ranking_case('c1_top10', '5,10')
+    ranking_case('c1_top20', '10,20')
+    m6, out6 = quiet(recr.ranking_performance)
+    json.dump({'measure': m6, 'stdout': out6}, open(os.path.join(OUT, 'g6_ranking_performance.json'), 'w'), indent=1)
+
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print('golden files:', sorted(os.listdir(OUT)), 'total bytes', tot)
+
+
+if __name__ == '__main__':
+    main()
