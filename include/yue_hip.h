@@ -1,0 +1,125 @@
+/*
+ * yue_hip.h -- C ABI of libyue_hip.so: the MI355X (gfx950) BPR training + top-N scoring path
+ * that replaces the NumPy loop of 0411tony/Yue behind its Recommender plugin surface.
+ *
+ * Plain pointers and sizes only; all pointers are HOST pointers owned by the caller and are
+ * borrowed for the duration of the call (NumPy owns P/Q).  Device memory lives
+ * behind the opaque context.  Every function returns 0 on success; otherwise a negative
+ * status and yue_last_error() holds a thread-local message (the reference's convention is
+ * print + exit(-1): tool/config.py:9-11, base/IterativeRecommender.py:64-66 -- the Python
+ * shim does exactly that with the message).
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   yue_set_factors / yue_get_factors   state contract of IterativeRecommender.initModel
+ *                                       (base/IterativeRecommender.py:36-39): P[m,k], Q[n,k] fp32 C-order
+ *   yue_set_interactions                userListen + userRecord iteration of BPR.buildModel
+ *                                       (recommender/cf/BPR.py:32-35,42-45; data/record.py:138-163)
+ *   yue_bpr_replay                      the epoch body recommender/cf/BPR.py:42-58 on an explicit
+ *                                       (u,i,j) stream, exact sequential semantics
+ *   yue_bpr_rounds / yue_bpr_epoch      the same triplet update in rounds (DESIGN.md "S-round"),
+ *                                       yue_bpr_epoch fuses the negative sampler of BPR.py:46-48
+ *   yue_sumsq                           the regulariser sums of BPR.py:59
+ *   yue_scores                          BPR.predict / IterativeRecommender.predict
+ *                                       (recommender/cf/BPR.py:131-134, base/IterativeRecommender.py:58-60)
+ *   yue_topn_scan                       the per-user mask + seed + overwrite-scan of
+ *                                       IterativeRecommender.evalRanking (base/IterativeRecommender.py:96-145)
+ *                                       and ranking_performance (:186-228)
+ */
+#ifndef YUE_HIP_H
+#define YUE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yue_ctx yue_ctx;
+
+#define YUE_OK              0
+#define YUE_ERR_ARG        -1   /* bad argument / call order */
+#define YUE_ERR_HIP        -2   /* HIP runtime error */
+#define YUE_ERR_FEW_ITEMS  -3   /* a user has fewer than N candidates (reference: IndexError) */
+#define YUE_ERR_COMM       -4   /* RCCL error */
+
+#define YUE_MAX_ATTEMPTS   64   /* negative-sampler attempts before a triplet is skipped */
+#define YUE_UNIQUE_ID_BYTES 128
+
+const char *yue_last_error(void);
+int yue_version(void);
+
+/* device = HIP ordinal.  HIP is initialised here, never earlier (fork-safety: yue.py:94-105). */
+int yue_ctx_create(int device, yue_ctx **out);
+int yue_ctx_destroy(yue_ctx *ctx);
+int yue_sync(yue_ctx *ctx);
+
+/* Factor matrices, fp32 row-major.  k <= 256. */
+int yue_set_factors(yue_ctx *ctx, const float *P, int64_t m, const float *Q, int64_t n, int k);
+int yue_get_factors(yue_ctx *ctx, float *P, float *Q);
+
+/*
+ * Training interactions of this context's item range (all items on one GPU).
+ *   indptr[m+1], indices[nnz]  sorted-unique listened items per user (negative rejection)
+ *   ev_ptr[m+1], ev_i[E]       events in userRecord order: user-major, users by ascending id,
+ *                              duplicates kept (one triplet per event, BPR.py:44)
+ */
+int yue_set_interactions(yue_ctx *ctx, const int64_t *indptr, const int32_t *indices,
+                         const int64_t *ev_ptr, const int32_t *ev_i);
+
+/* Exact sequential semantics of BPR.py:42-58 on explicit triplets (dependency-levelled on the
+ * device).  j[t] < 0 skips the triplet.  nll_out = sum of -log(s). */
+int yue_bpr_replay(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
+                   double lr, double regU, double regI, double *nll_out);
+
+/* Explicit triplets, S-round semantics: rounds are round_ptr[r]..round_ptr[r+1] (n_rounds+1 entries). */
+int yue_bpr_rounds(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j,
+                   const int64_t *round_ptr, int64_t n_rounds,
+                   double lr, double regU, double regI, double *nll_out);
+
+/*
+ * One epoch over the uploaded events with the fused counter-based negative sampler.
+ * Rounds are round_events consecutive events (on a communicator: user-aligned blocks of about
+ * that many events, identical user ranges on every rank, user-factor gradients all-reduced).
+ * Outputs: nll (sum of -log s over this rank's triplets), sums of squares of P and of this
+ * rank's Q after the epoch (for BPR.py:59).  Any output pointer may be NULL.
+ */
+int yue_bpr_epoch(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int64_t round_events,
+                  double lr, double regU, double regI,
+                  double *nll_out, double *sumsqP_out, double *sumsqQ_out);
+
+/* Negatives the fused sampler draws for (seed, epoch): j_out[E], -1 where all attempts were rejected. */
+int yue_sample_negatives(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int32_t *j_out);
+
+int yue_sumsq(yue_ctx *ctx, double *sumsqP_out, double *sumsqQ_out);
+
+/* predict(user): scores of all n items in id order, fp32, k-ascending fused-multiply-add chain. */
+int yue_scores(yue_ctx *ctx, int32_t user, float *out_n);
+
+/*
+ * evalRanking's selection for nu users.  Masked items per user come from mask_indptr[nu+1] /
+ * mask_indices (rows sorted ascending, indexed by position in users[]); pass NULL for both to
+ * mask the uploaded training items (evalRanking).  out_ids[nu*N], out_scores[nu*N], 1 <= N <= 100 (the reference caps N at 100, :84-86); k <= 128.
+ * Returns YUE_ERR_FEW_ITEMS if some user has fewer than N candidates (their rows are -1 / -inf).
+ */
+int yue_topn_scan(yue_ctx *ctx, const int32_t *users, int64_t nu, int N,
+                  const int64_t *mask_indptr, const int32_t *mask_indices,
+                  int32_t *out_ids, float *out_scores);
+
+/* Timing of the dominant training kernel with HIP events on the library's stream.
+ * stride = 0 disables; otherwise every stride-th launch is bracketed. */
+int yue_set_kernel_timing(yue_ctx *ctx, int stride);
+int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_timed, int64_t *triplets_timed);
+/* Time of the last yue_topn_scan's scoring kernel (HIP events), and its candidate-event count. */
+int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events);
+
+/* Multi-GPU (one process per GPU, RCCL over xGMI).  Rank 0 creates the id, the caller ships
+ * the 128 bytes to the other ranks (any side channel), every rank calls yue_comm_init. */
+int yue_comm_unique_id(void *id128_out);
+int yue_comm_init(yue_ctx *ctx, const void *id128, int rank, int nranks);
+/* Sum a double across ranks (loss terms); identity without a communicator. */
+int yue_allreduce_f64(yue_ctx *ctx, double *vals, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

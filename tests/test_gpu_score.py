@@ -1,0 +1,137 @@
+"""GPU parity of predict() and the evalRanking selection, through the C ABI.
+
+Integer ranking lists must be bit-exact (BASELINE.json north_star): the GPU scores use the same
+k-ascending fp32 fma chain as the oracle, so lists AND scores are compared for equality.  On the
+reference's own trained factors the lists are also compared with the reference's golden lists.
+"""
+import numpy as np
+import pytest
+
+from util import csr_from_events, gz, mask_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from yue_amd._shim import Device
+    d = Device(0, raise_errors=True)
+    yield d
+    d.close()
+
+
+def _rand_problem(m, n, k, per_user, seed, signed=True):
+    rs = np.random.RandomState(seed)
+    P = rs.randn(m, k).astype(np.float32) if signed else (rs.rand(m, k).astype(np.float32) / 10)
+    Q = rs.randn(n, k).astype(np.float32) if signed else (rs.rand(n, k).astype(np.float32) / 10)
+    rows = [np.sort(rs.choice(n, size=min(n - 1, rs.randint(0, per_user + 1)), replace=False)) for _ in range(m)]
+    indptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
+    indices = (np.concatenate(rows) if indptr[-1] else np.zeros(0)).astype(np.int32)
+    return P, Q, indptr, indices
+
+
+def test_predict_is_bit_exact_with_oracle(dev, orc):
+    for (m, n, k) in [(5, 1000, 10), (3, 777, 64), (4, 2049, 128), (2, 50, 33)]:
+        P, Q, _, _ = _rand_problem(m, n, k, 0, seed=k)
+        dev.set_factors(P, Q)
+        for u in range(m):
+            assert np.array_equal(dev.scores(u), orc.scores(P, Q, u))
+
+
+@pytest.mark.parametrize('tag,N', [('c1_top10', 10), ('c1_top20', 20)])
+def test_lists_match_reference_golden(dev, orc, tag, N):
+    # evalRanking (IterativeRecommender.py:93-145) on the reference's trained factors
+    z = gz('g4_c1_k10_e1.npz')
+    ev = gz('g2_events_c1.npz')
+    g = gz('g5_%s.npz' % tag)
+    m = int(z['m'])
+    indptr, indices = csr_from_events(ev['ev_u'], ev['ev_i'], m)
+    ev_ptr = np.zeros(m + 1, np.int64)
+    np.add.at(ev_ptr, ev['ev_u'] + 1, 1)
+    ev_ptr = np.cumsum(ev_ptr)
+    dev.set_factors(z['P'], z['Q'])
+    dev.set_interactions(indptr, indices, ev_ptr, ev['ev_i'])
+    users = g['test_users']
+    ids, sc = dev.topn_scan(users, N)                       # mask = uploaded training items
+    assert np.array_equal(ids, g['rec_ids'])                # the reference's integer lists
+    mp, mi = mask_rows(indptr, indices, users)
+    oid, osc, rc = orc.topn_scan(z['P'], z['Q'], users, N, mp, mi)
+    assert rc == 0 and np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    ids2, sc2 = dev.topn_scan(users, N, mp, mi)             # explicit mask, same rows
+    assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
+
+
+@pytest.mark.parametrize('m,n,k,N,per_user', [
+    (130, 1000, 10, 10, 30),      # two workgroups, partial second one
+    (37, 333, 64, 5, 300),        # n not a multiple of 32, dense masks
+    (300, 4099, 128, 20, 60),
+    (64, 2000, 128, 100, 10),     # largest N
+    (33, 500, 16, 1, 5),
+    (10, 97, 7, 3, 20),           # odd k (zero padded), tiny
+])
+def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
+    P, Q, indptr, indices = _rand_problem(m, n, k, per_user, seed=m + n + k + N)
+    dev.set_factors(P, Q)
+    users = np.random.RandomState(3).permutation(m).astype(np.int32)
+    mp, mi = mask_rows(indptr, indices, users)
+    ids, sc = dev.topn_scan(users, N, mp, mi)
+    oid, osc, rc = orc.topn_scan(P, Q, users, N, mp, mi)
+    assert rc == 0
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(sc, osc)
+    ms, events = dev.scan_stats()
+    assert ms > 0 and events >= len(users) * N
+
+
+def test_scan_with_ties_and_duplicates(dev, orc):
+    # quantised factors give many equal scores: ties go after equals, stable seed order
+    rs = np.random.RandomState(9)
+    m, n, k, N = 40, 600, 8, 10
+    P = rs.randint(-2, 3, size=(m, k)).astype(np.float32)
+    Q = rs.randint(-2, 3, size=(n, k)).astype(np.float32)
+    indptr = np.zeros(m + 1, np.int64)
+    indices = np.zeros(0, np.int32)
+    dev.set_factors(P, Q)
+    users = np.arange(m, dtype=np.int32)
+    ids, sc = dev.topn_scan(users, N, indptr, indices)
+    oid, osc, _ = orc.topn_scan(P, Q, users, N, indptr, indices)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+
+
+def test_too_few_candidates_raises_like_the_reference(dev):
+    P, Q, _, _ = _rand_problem(2, 12, 4, 0, seed=1)
+    dev.set_factors(P, Q)
+    mp = np.array([0, 9, 9], np.int64)
+    mi = np.arange(9, dtype=np.int32)
+    with pytest.raises(IndexError):                      # IterativeRecommender.py:126
+        dev.topn_scan(np.array([0, 1], np.int32), 5, mp, mi)
+    ids, _ = dev.topn_scan(np.array([1], np.int32), 5, np.array([0, 0], np.int64), np.zeros(0, np.int32))
+    assert ids.shape == (1, 5) and (ids >= 0).all()
+
+
+def test_full_size_scan_properties(dev, orc):
+    # C5-like slice: 200K items, k=128, N=20; properties + oracle on a few users
+    rs = np.random.RandomState(5)
+    m, n, k, N = 512, 200000, 128, 20
+    P = rs.rand(m, k).astype(np.float32) / 10
+    Q = rs.rand(n, k).astype(np.float32) / 10
+    indptr = np.arange(m + 1, dtype=np.int64) * 40
+    indices = np.sort(rs.randint(0, n, size=(m, 40)), axis=1)
+    indices[:, 1:] += (np.diff(indices, axis=1) == 0)          # crude de-dup keeps rows strictly sorted mostly
+    indices = np.sort(indices, axis=1)
+    ok = (np.diff(indices, axis=1) > 0).all(axis=1)
+    users = np.where(ok)[0].astype(np.int32)
+    dev.set_factors(P, Q)
+    mp, mi = mask_rows(indptr, indices.reshape(-1).astype(np.int32), users)
+    ids, sc = dev.topn_scan(users, N, mp, mi)
+    # slot 0 is the global maximum over candidates; scores are non-increasing; no masked item listed
+    assert (np.diff(sc, axis=1) <= 0).all()
+    for t in range(0, len(users), 37):
+        s = dev.scores(int(users[t]))
+        s[mi[mp[t]:mp[t + 1]]] = -np.inf
+        assert ids[t, 0] == int(np.argmax(s)) and sc[t, 0] == s.max()
+        assert not set(ids[t].tolist()) & set(mi[mp[t]:mp[t + 1]].tolist())
+        assert np.array_equal(sc[t], dev.scores(int(users[t]))[ids[t]])
+    sub = slice(0, 24)
+    oid, osc, _ = orc.topn_scan(P, Q, users[sub], N, *mask_rows(indptr, indices.reshape(-1).astype(np.int32), users[sub]))
+    assert np.array_equal(ids[sub], oid) and np.array_equal(sc[sub], osc)

@@ -1,0 +1,192 @@
+"""GPU parity of the training path, through the C ABI (yue_amd/_shim.py -> libyue_hip.so).
+
+Checker = oracle/ (pinned to the reference by tests/test_oracle_golden.py) and the reference's own
+golden outputs.  Tolerances: BASELINE.json north_star -- factor matrices within 1e-5 rel fp32
+(rel = max|a-b| / max|b|); integer work (sampler) bit-exact.
+"""
+import numpy as np
+import pytest
+
+from yue_amd import synth
+from util import gz, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from yue_amd._shim import Device
+    d = Device(0, raise_errors=True)
+    yield d
+    d.close()
+
+
+def _golden(tag):
+    z = gz('g4_%s.npz' % tag)
+    iters = int(z['iters'])
+    return z, iters, len(z['u']) // iters
+
+
+@pytest.mark.parametrize('tag', ['c1_k10_e1', 'd2_k64_e1', 'd3_k128_e2'])
+def test_replay_matches_reference_and_oracle(dev, orc, tag):
+    # BPR.py:42-58 on the reference's own triplet stream (lRate stays 0.02 over these epochs)
+    z, iters, E = _golden(tag)
+    m, n, k, seed = int(z['m']), int(z['n']), int(z['k']), int(z['seed'])
+    P0, Q0 = synth.init_factors(m, n, k, seed)
+    Po, Qo = P0.copy(), Q0.copy()
+    dev.set_factors(P0, Q0)
+    lr = 0.02
+    nll_g = nll_o = 0.0
+    for ep in range(iters):
+        sl = slice(ep * E, (ep + 1) * E)
+        nll_g = dev.bpr_replay(z['u'][sl], z['i'][sl], z['j'][sl], lr, 0.01, 0.01)
+        nll_o = orc.bpr_sequential(Po, Qo, z['u'][sl], z['i'][sl], z['j'][sl], lr, 0.01, 0.01)
+        assert abs(nll_g - nll_o) <= 1e-9 * abs(nll_o)
+    P, Q = dev.get_factors()
+    # same dot order as the oracle: differences can only come from exp/log last-bit rounding
+    assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6
+    print('bit-exact vs oracle: P %.4f Q %.4f' % (np.mean(P == Po), np.mean(Q == Qo)))
+    # and the reference's own result
+    assert rel_err(P, z['P']) < TOL and rel_err(Q, z['Q']) < TOL
+    sp, sq = dev.sumsq()
+    assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
+    loss = np.float32(nll_g) + (np.float32(0.01) * np.float32(sp) + np.float32(0.01) * np.float32(sq))
+    assert abs(float(loss) - float(z['loss'])) <= TOL * abs(float(z['loss']))
+
+
+def test_replay_edge_cases(dev, orc):
+    rs = np.random.RandomState(1)
+    m, n, k = 7, 9, 33                       # k not a multiple of 32, tiny shapes
+    P0 = rs.rand(m, k).astype(np.float32) / 10
+    Q0 = rs.rand(n, k).astype(np.float32) / 10
+    u = np.array([0, 0, 0, 3, 6, 0, 3], np.int32)
+    i = np.array([1, 1, 2, 8, 0, 1, 8], np.int32)
+    j = np.array([2, 4, 1, 0, -1, 5, 7], np.int32)   # one skipped triplet, repeated rows, i/j swapped roles
+    dev.set_factors(P0, Q0)
+    nll = dev.bpr_replay(u, i, j, 0.05, 0.02, 0.03)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_sequential(Po, Qo, u, i, j, 0.05, 0.02, 0.03)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(nll - nll_o) < 1e-9 * nll_o
+    # empty stream is a no-op
+    assert dev.bpr_replay(u[:0], i[:0], j[:0], 0.05, 0.02, 0.03) == 0.0
+    P2, Q2 = dev.get_factors()
+    assert np.array_equal(P, P2) and np.array_equal(Q, Q2)
+    from yue_amd._shim import YueHipError
+    with pytest.raises(YueHipError):
+        dev.bpr_replay(np.array([7], np.int32), np.array([0], np.int32), np.array([1], np.int32), 0.05, 0.02, 0.03)
+
+
+@pytest.mark.parametrize('tag,W', [('c1_k10_e1', 64), ('c1_k10_e1', 1000), ('d2_k64_e1', 257), ('d3_k128_e2', 4096)])
+def test_rounds_match_oracle(dev, orc, tag, W):
+    z, iters, E = _golden(tag)
+    m, n, k = int(z['m']), int(z['n']), int(z['k'])
+    P0, Q0 = synth.init_factors(m, n, k, 11)
+    T = E
+    rp = np.unique(np.concatenate([np.arange(0, T, W), [T]])).astype(np.int64)
+    dev.set_factors(P0, Q0)
+    nll = dev.bpr_rounds(z['u'][:T], z['i'][:T], z['j'][:T], rp, 0.02, 0.01, 0.01)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_rounds(Po, Qo, z['u'][:T], z['i'][:T], z['j'][:T], rp, 0.02, 0.01, 0.01)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
+    assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+
+
+def test_rounds_of_one_reduce_to_the_reference_loop(dev):
+    # S-round with one triplet per round is the sequential loop: compare with the reference's output
+    z, iters, E = _golden('d2_k64_e1')
+    m, n, k, seed = int(z['m']), int(z['n']), int(z['k']), int(z['seed'])
+    P0, Q0 = synth.init_factors(m, n, k, seed)
+    dev.set_factors(P0, Q0)
+    T = E
+    dev.bpr_rounds(z['u'][:T], z['i'][:T], z['j'][:T], np.arange(T + 1), 0.02, 0.01, 0.01)
+    P, Q = dev.get_factors()
+    assert rel_err(P, z['P']) < TOL and rel_err(Q, z['Q']) < TOL
+
+
+def _synth_problem(m, n, d, k, seed=5):
+    data = synth.make_arrays(m, n, d, seed=seed)
+    P0, Q0 = synth.init_factors(m, n, k, seed)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    return data, P0, Q0, ev_u
+
+
+@pytest.mark.parametrize('m,n,d,k,W', [(300, 400, 20, 10, 128), (500, 257, 30, 64, 1000), (2000, 3000, 50, 128, 8192)])
+def test_fused_epoch_matches_oracle(dev, orc, m, n, d, k, W):
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    seed = 987654321
+    Po, Qo = P0.copy(), Q0.copy()
+    E = len(ev_u)
+    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    for epoch in range(2):
+        # integer work: the fused sampler's negatives are bit-exact with the oracle's
+        j_gpu = dev.sample_negatives(seed, epoch)
+        j_orc = orc.sample_counter(seed, epoch, ev_u, n, data['indptr'], data['indices'])
+        assert np.array_equal(j_gpu, j_orc)
+        nll, sp, sq = dev.bpr_epoch(seed, epoch, W, 0.02, 0.01, 0.01)
+        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j_orc, rp, 0.02, 0.01, 0.01)
+        P, Q = dev.get_factors()
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
+        assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+        assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
+
+
+def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):
+    # user 0 listened to all but one item (sampler mostly rejects), user 1 has no events at all
+    m, n, k = 3, 40, 16
+    rows = [np.arange(39), np.zeros(0, int), np.array([3, 7])]
+    indptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
+    indices = np.concatenate(rows).astype(np.int32)
+    ev_ptr = np.array([0, 39, 39, 41], np.int64)
+    ev_i = np.concatenate([np.arange(39), [3, 7]]).astype(np.int32)
+    ev_u = np.repeat(np.arange(3, dtype=np.int32), np.diff(ev_ptr))
+    P0, Q0 = synth.init_factors(m, n, k, 3)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(indptr, indices, ev_ptr, ev_i)
+    j_gpu = dev.sample_negatives(77, 0)
+    j_orc = orc.sample_counter(77, 0, ev_u, n, indptr, indices)
+    assert np.array_equal(j_gpu, j_orc)
+    assert set(j_orc[:39].tolist()) <= {39, -1}
+    nll, _, _ = dev.bpr_epoch(77, 0, 16, 0.02, 0.01, 0.01)
+    Po, Qo = P0.copy(), Q0.copy()
+    rp = np.array([0, 16, 32, 41], np.int64)
+    nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j_orc, rp, 0.02, 0.01, 0.01)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
+    assert np.array_equal(P[1], P0[1])
+
+
+def test_full_size_properties(dev):
+    # BASELINE config 2 shape (100K x 50K, k=64): size-independent properties instead of the oracle
+    m, n, d, k = 100000, 50000, 50, 64
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=20260001)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    E = len(ev_u)
+    j = dev.sample_negatives(1, 0)
+    assert (j >= 0).all() and (j < n).all()
+    # no sampled negative is a listened item
+    key = np.repeat(np.arange(m, dtype=np.int64), np.diff(data['indptr'])) * n + data['indices']
+    assert not np.isin(ev_u.astype(np.int64) * n + j, key).any()
+    losses = []
+    for epoch in range(3):
+        nll, sp, sq = dev.bpr_epoch(1, epoch, 32768, 0.05, 0.01, 0.01)
+        assert np.isfinite(nll) and np.isfinite(sp) and np.isfinite(sq)
+        losses.append(nll)
+    assert losses[2] < losses[1] < losses[0] < E * np.log(2) * 1.01
+    # a second context replays to the same result (atomics only reorder fp32 sums)
+    P, Q = dev.get_factors()
+    from yue_amd._shim import Device
+    d2 = Device(0, raise_errors=True)
+    d2.set_factors(P0, Q0)
+    d2.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    for epoch in range(3):
+        d2.bpr_epoch(1, epoch, 32768, 0.05, 0.01, 0.01)
+    P2, Q2 = d2.get_factors()
+    d2.close()
+    assert rel_err(P2, P) < TOL and rel_err(Q2, Q) < TOL

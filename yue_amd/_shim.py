@@ -1,0 +1,218 @@
+"""ctypes binding of libyue_hip.so (include/yue_hip.h).
+
+This is the only route from the Python plugin surface to the numeric hot path: there is no
+CPU fallback.  If the library is missing or no MI355X is visible, calls fail loudly in the
+reference's style -- print the message, exit(-1) (tool/config.py:9-11,
+base/IterativeRecommender.py:64-66) -- or raise YueHipError when ``raise_errors`` is set
+(tests use that).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libyue_hip.so')
+
+OK, ERR_ARG, ERR_HIP, ERR_FEW_ITEMS, ERR_COMM = 0, -1, -2, -3, -4
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/yue_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy', 'yue_sync',
+           'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
+           'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
+           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats',
+           'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64']
+
+
+class YueHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super(YueHipError, self).__init__('libyue_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libyue_hip.so; never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YueHipError(ERR_HIP, 'HIP library not built: %s (run `make -C yue_amd/csrc` or __graft_entry__.build())' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.yue_last_error.restype = C.c_char_p
+        for name in SYMBOLS[1:]:
+            getattr(lib, name).restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def comm_unique_id():
+    lib = load_library()
+    buf = (C.c_ubyte * UNIQUE_ID_BYTES)()
+    rc = lib.yue_comm_unique_id(buf)
+    if rc != OK:
+        raise YueHipError(rc, lib.yue_last_error().decode())
+    return bytes(buf)
+
+
+class Device(object):
+    """One HIP context = one GPU (one process per GPU)."""
+
+    def __init__(self, device=0, raise_errors=False):
+        self._lib = load_library()
+        self._raise = raise_errors
+        self._ctx = C.c_void_p()
+        self.m = self.n = self.k = self.E = 0
+        self._chk(self._lib.yue_ctx_create(C.c_int(device), C.byref(self._ctx)))
+
+    # reference convention: print, exit(-1)
+    def _chk(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.yue_last_error().decode()
+        if self._raise:
+            raise YueHipError(rc, msg)
+        print(msg)
+        exit(-1)
+
+    def close(self):
+        if self._ctx:
+            self._lib.yue_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self._lib.yue_sync(self._ctx))
+
+    # -- state ------------------------------------------------------------------------
+    def set_factors(self, P, Q):
+        P, pp = _f32(P)
+        Q, qp = _f32(Q)
+        assert P.ndim == 2 and Q.ndim == 2 and P.shape[1] == Q.shape[1]
+        self.m, self.k = P.shape
+        self.n = Q.shape[0]
+        self._chk(self._lib.yue_set_factors(self._ctx, pp, C.c_int64(self.m), qp, C.c_int64(self.n), C.c_int(self.k)))
+
+    def get_factors(self, P=None, Q=None):
+        """Copies the device factors into P, Q (allocated when None) and returns them."""
+        if P is None:
+            P = np.empty((self.m, self.k), np.float32)
+        if Q is None:
+            Q = np.empty((self.n, self.k), np.float32)
+        assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous
+        self._chk(self._lib.yue_get_factors(self._ctx, P.ctypes.data_as(C.POINTER(C.c_float)), Q.ctypes.data_as(C.POINTER(C.c_float))))
+        return P, Q
+
+    def set_interactions(self, indptr, indices, ev_ptr, ev_i):
+        indptr, a = _i64(indptr)
+        indices, b = _i32(indices if len(indices) else np.zeros(1, np.int32))
+        ev_ptr, c = _i64(ev_ptr)
+        ev_i, d = _i32(ev_i if len(ev_i) else np.zeros(1, np.int32))
+        assert len(indptr) == self.m + 1 and len(ev_ptr) == self.m + 1
+        self.E = int(ev_ptr[-1])
+        self._chk(self._lib.yue_set_interactions(self._ctx, a, b, c, d))
+
+    # -- training -----------------------------------------------------------------------
+    def bpr_replay(self, u, i, j, lr, regU, regI):
+        u, a = _i32(u)
+        i, b = _i32(i)
+        j, c = _i32(j)
+        nll = C.c_double()
+        self._chk(self._lib.yue_bpr_replay(self._ctx, a, b, c, C.c_int64(len(u)), C.c_double(lr), C.c_double(regU), C.c_double(regI), C.byref(nll)))
+        return nll.value
+
+    def bpr_rounds(self, u, i, j, round_ptr, lr, regU, regI):
+        u, a = _i32(u)
+        i, b = _i32(i)
+        j, c = _i32(j)
+        rp, d = _i64(round_ptr)
+        nll = C.c_double()
+        self._chk(self._lib.yue_bpr_rounds(self._ctx, a, b, c, d, C.c_int64(len(rp) - 1), C.c_double(lr), C.c_double(regU), C.c_double(regI), C.byref(nll)))
+        return nll.value
+
+    def bpr_epoch(self, seed, epoch, round_events, lr, regU, regI):
+        """Returns (nll, sumsqP, sumsqQ) after one fused-sampler epoch."""
+        nll, sp, sq = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self._lib.yue_bpr_epoch(self._ctx, C.c_uint64(seed), C.c_uint32(epoch), C.c_int64(round_events), C.c_double(lr), C.c_double(regU),
+                                          C.c_double(regI), C.byref(nll), C.byref(sp), C.byref(sq)))
+        return nll.value, sp.value, sq.value
+
+    def sample_negatives(self, seed, epoch):
+        j = np.empty(max(self.E, 1), np.int32)
+        self._chk(self._lib.yue_sample_negatives(self._ctx, C.c_uint64(seed), C.c_uint32(epoch), j.ctypes.data_as(C.POINTER(C.c_int32))))
+        return j[:self.E]
+
+    def sumsq(self):
+        sp, sq = C.c_double(), C.c_double()
+        self._chk(self._lib.yue_sumsq(self._ctx, C.byref(sp), C.byref(sq)))
+        return sp.value, sq.value
+
+    # -- scoring ------------------------------------------------------------------------
+    def scores(self, user):
+        out = np.empty(self.n, np.float32)
+        self._chk(self._lib.yue_scores(self._ctx, C.c_int32(user), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def topn_scan(self, users, N, mask_indptr=None, mask_indices=None):
+        """(ids[nu,N] int32, scores[nu,N] float32).  Raises IndexError like the reference
+        (base/IterativeRecommender.py:126) when a user has fewer than N candidates."""
+        users, up = _i32(users)
+        ids = np.empty((len(users), N), np.int32)
+        sc = np.empty((len(users), N), np.float32)
+        if mask_indptr is None:
+            mp = mi = None
+        else:
+            mask_indptr, mp = _i64(mask_indptr)
+            mask_indices, mi = _i32(mask_indices if len(mask_indices) else np.zeros(1, np.int32))
+        rc = self._lib.yue_topn_scan(self._ctx, up, C.c_int64(len(users)), C.c_int(N), mp, mi,
+                                     ids.ctypes.data_as(C.POINTER(C.c_int32)), sc.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc == ERR_FEW_ITEMS:
+            raise IndexError('list index out of range')
+        self._chk(rc)
+        return ids, sc
+
+    def scan_stats(self):
+        ms, ev = C.c_double(), C.c_int64()
+        self._chk(self._lib.yue_get_scan_stats(self._ctx, C.byref(ms), C.byref(ev)))
+        return ms.value, ev.value
+
+    # -- measurement ----------------------------------------------------------------------
+    def set_kernel_timing(self, stride):
+        self._chk(self._lib.yue_set_kernel_timing(self._ctx, C.c_int(stride)))
+
+    def get_kernel_timing(self):
+        ms, nl, nt = C.c_double(), C.c_int64(), C.c_int64()
+        self._chk(self._lib.yue_get_kernel_timing(self._ctx, C.byref(ms), C.byref(nl), C.byref(nt)))
+        return ms.value, nl.value, nt.value
+
+    # -- multi-GPU ----------------------------------------------------------------------
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._chk(self._lib.yue_comm_init(self._ctx, buf, C.c_int(rank), C.c_int(nranks)))
+
+    def allreduce_f64(self, vals):
+        arr = (C.c_double * len(vals))(*vals)
+        self._chk(self._lib.yue_allreduce_f64(self._ctx, arr, C.c_int(len(vals))))
+        return list(arr)

@@ -1,0 +1,575 @@
+// libyue_hip.so -- C ABI (include/yue_hip.h) over the gfx950 kernels.
+// Host side: device buffers behind an opaque context, dependency levelling for exact replay,
+// round scheduling for the fused epoch, RCCL all-reduce of user-factor differences.
+#include "../../include/yue_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "train_kernels.hpp"
+#include "score_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(YUE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+#define NCCLCHK(expr)                                                                             \
+    do {                                                                                          \
+        ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail(YUE_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));        \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; n = 0; if (e != hipSuccess) return e; }
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct yue_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t m = 0, n = 0, E = 0, nnz = 0;
+    int k = 0;
+    bool have_factors = false, have_inter = false;
+    DevBuf<float> P, Q, dP, dQ;
+    DevBuf<uint32_t> dirtyP, dirtyQ;
+    DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
+    DevBuf<int64_t> indptr;
+    DevBuf<int32_t> xu, xi, xj;          // explicit triplets (replay / rounds)
+    DevBuf<double> scal;                 // [kNllSlots] nll slots + [8] scalars
+    std::vector<int64_t> h_ev_ptr;       // host copy: user -> first event
+    // scoring scratch
+    DevBuf<int32_t> s_users, s_ids, s_mask_idx, s_flags;
+    DevBuf<int64_t> s_mask_ptr;
+    DevBuf<float> s_scores, s_row;
+    double scan_ms = 0.0;
+    int64_t scan_events = 0;
+    // kernel timing
+    int timing_stride = 0;
+    int64_t launch_counter = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int64_t> ev_triplets;
+    size_t ev_used = 0;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+namespace {
+
+int kr_of(int k) { return k <= 32 ? 1 : k <= 64 ? 2 : k <= 128 ? 4 : 8; }
+
+yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
+    yue::TrainArgs a{};
+    a.P = c->P.p; a.Q = c->Q.p; a.dP = c->dP.p; a.dQ = c->dQ.p;
+    a.dirtyP = c->dirtyP.p; a.dirtyQ = c->dirtyQ.p;
+    a.ev_u = c->ev_u.p; a.ev_i = c->ev_i.p; a.ev_j = c->ev_j.p;
+    a.indptr = c->indptr.p; a.indices = c->indices.p;
+    a.nll_slots = c->scal.p;
+    a.m = c->m; a.n = c->n; a.k = c->k;
+    a.lr = lr;
+    a.ru = (float)(lr * regU);      // BPR.py:55: python-float product, cast to fp32 by NumPy
+    a.ri = (float)(lr * regI);
+    a.neg_lo = 0; a.neg_range = (int32_t)c->n;
+    return a;
+}
+
+template <bool SAMPLE, bool DIRECT>
+void launch_update(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int tpw) {
+    const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (kr_of(c->k)) {
+        case 1: hipLaunchKernelGGL((yue::k_bpr_update<1, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
+        case 2: hipLaunchKernelGGL((yue::k_bpr_update<2, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
+        case 4: hipLaunchKernelGGL((yue::k_bpr_update<4, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
+        default: hipLaunchKernelGGL((yue::k_bpr_update<8, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
+    }
+}
+
+// Bracket every timing_stride-th update launch with HIP events on the library's stream.
+template <bool SAMPLE, bool DIRECT>
+int timed_update(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int tpw) {
+    const bool timed = c->timing_stride > 0 && (c->launch_counter++ % c->timing_stride) == 0;
+    if (timed) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t s, t;
+            HIPCHK(hipEventCreate(&s));
+            HIPCHK(hipEventCreate(&t));
+            c->ev_pool.emplace_back(s, t);
+            c->ev_triplets.push_back(0);
+        }
+        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].first, c->stream));
+    }
+    launch_update<SAMPLE, DIRECT>(c, a, e0, e1, tpw);
+    if (timed) {
+        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
+        c->ev_triplets[c->ev_used] = e1 - e0;
+        c->ev_used++;
+    }
+    return YUE_OK;
+}
+
+void launch_apply(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int apply_p) {
+    const int64_t waves = (e1 - e0 + 31) / 32;
+    hipLaunchKernelGGL(yue::k_apply_round, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, a, e0, e1, apply_p);
+}
+
+int tpw_for(int64_t round_events) {
+    // enough waves to cover the chip (256 CUs x >= 8 waves) before a wave takes more events
+    int tpw = (int)std::min<int64_t>(64, std::max<int64_t>(1, round_events / 4096));
+    return tpw;
+}
+
+int zero_scalars(yue_ctx *c) {
+    HIPCHK(hipMemsetAsync(c->scal.p, 0, (yue::kNllSlots + 8) * sizeof(double), c->stream));
+    return YUE_OK;
+}
+
+int read_scalars(yue_ctx *c, double *nll, double *sp, double *sq) {
+    double *sc = c->scal.p + yue::kNllSlots;
+    hipLaunchKernelGGL(yue::k_sum_slots, dim3(1), dim3(64), 0, c->stream, c->scal.p, yue::kNllSlots, sc);
+    double h[3];
+    HIPCHK(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nll) *nll = h[0];
+    if (sp) *sp = h[1];
+    if (sq) *sq = h[2];
+    return YUE_OK;
+}
+
+int sumsq_async(yue_ctx *c) {
+    double *sc = c->scal.p + yue::kNllSlots;
+    HIPCHK(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(yue::k_sumsq, dim3(2048), dim3(256), 0, c->stream, c->P.p, c->m * c->k, sc + 1);
+    hipLaunchKernelGGL(yue::k_sumsq, dim3(2048), dim3(256), 0, c->stream, c->Q.p, c->n * c->k, sc + 2);
+    return YUE_OK;
+}
+
+int upload_triplets(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T) {
+    for (int64_t t = 0; t < T; ++t) {
+        if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] >= c->n)
+            return fail(YUE_ERR_ARG, "triplet " + std::to_string(t) + " out of range");
+    }
+    HIPCHK(c->xu.resize(T)); HIPCHK(c->xi.resize(T)); HIPCHK(c->xj.resize(T));
+    HIPCHK(hipMemcpyAsync(c->xu.p, u, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->xi.p, i, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->xj.p, j, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    return YUE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *yue_last_error(void) { return g_err.c_str(); }
+int yue_version(void) { return 1; }
+
+int yue_ctx_create(int device, yue_ctx **out) {
+    if (!out) return fail(YUE_ERR_ARG, "yue_ctx_create: out is NULL");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(YUE_ERR_HIP, "no HIP device visible: libyue_hip needs an MI355X (no CPU fallback exists)");
+    if (device < 0 || device >= ndev) return fail(YUE_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    yue_ctx *c = new yue_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c->scal.resize(yue::kNllSlots + 8));
+    *out = c;
+    return YUE_OK;
+}
+
+int yue_ctx_destroy(yue_ctx *c) {
+    if (!c) return YUE_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
+    c->dirtyP.release(); c->dirtyQ.release();
+    c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
+    c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
+    c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
+    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return YUE_OK;
+}
+
+int yue_sync(yue_ctx *c) {
+    if (!c) return fail(YUE_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
+}
+
+int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64_t n, int k) {
+    if (!c || !P || !Q) return fail(YUE_ERR_ARG, "yue_set_factors: null argument");
+    if (m <= 0 || n <= 0 || k <= 0 || k > 256) return fail(YUE_ERR_ARG, "yue_set_factors: need m,n > 0 and 1 <= k <= 256");
+    if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: ids must fit int32");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->have_inter && (m != c->m)) return fail(YUE_ERR_ARG, "yue_set_factors: m differs from the uploaded interactions");
+    c->m = m; c->n = n; c->k = k;
+    HIPCHK(c->P.resize(m * k)); HIPCHK(c->Q.resize(n * k));
+    HIPCHK(c->dP.resize(m * k)); HIPCHK(c->dQ.resize(n * k));
+    HIPCHK(c->dirtyP.resize(m)); HIPCHK(c->dirtyQ.resize(n));
+    HIPCHK(hipMemcpyAsync(c->P.p, P, m * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->Q.p, Q, n * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->dP.p, 0, m * k * sizeof(float), c->stream));
+    HIPCHK(hipMemsetAsync(c->dQ.p, 0, n * k * sizeof(float), c->stream));
+    HIPCHK(hipMemsetAsync(c->dirtyP.p, 0, m * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->dirtyQ.p, 0, n * sizeof(uint32_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_factors = true;
+    return YUE_OK;
+}
+
+int yue_get_factors(yue_ctx *c, float *P, float *Q) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_get_factors: no factors uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    if (P) HIPCHK(hipMemcpyAsync(P, c->P.p, c->m * c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (Q) HIPCHK(hipMemcpyAsync(Q, c->Q.p, c->n * c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
+}
+
+int yue_set_interactions(yue_ctx *c, const int64_t *indptr, const int32_t *indices, const int64_t *ev_ptr, const int32_t *ev_i) {
+    if (!c || !indptr || !indices || !ev_ptr || !ev_i) return fail(YUE_ERR_ARG, "yue_set_interactions: null argument");
+    if (!c->have_factors) return fail(YUE_ERR_ARG, "yue_set_interactions: call yue_set_factors first (m, n)");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t m = c->m, n = c->n;
+    if (indptr[0] != 0 || ev_ptr[0] != 0) return fail(YUE_ERR_ARG, "yue_set_interactions: indptr[0] and ev_ptr[0] must be 0");
+    for (int64_t u = 0; u < m; ++u) {
+        if (indptr[u + 1] < indptr[u] || ev_ptr[u + 1] < ev_ptr[u]) return fail(YUE_ERR_ARG, "yue_set_interactions: offsets must be non-decreasing");
+        for (int64_t t = indptr[u]; t < indptr[u + 1]; ++t) {
+            if (indices[t] < 0 || indices[t] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: item id out of range");
+            if (t > indptr[u] && indices[t] <= indices[t - 1]) return fail(YUE_ERR_ARG, "yue_set_interactions: rows must be sorted and unique");
+        }
+        if (indptr[u + 1] - indptr[u] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: a user listened to every item (the reference's sampler would never return, BPR.py:47)");
+    }
+    const int64_t nnz = indptr[m], E = ev_ptr[m];
+    std::vector<int32_t> evu((size_t)E);
+    for (int64_t u = 0; u < m; ++u)
+        for (int64_t e = ev_ptr[u]; e < ev_ptr[u + 1]; ++e) {
+            if (ev_i[e] < 0 || ev_i[e] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: event item out of range");
+            evu[(size_t)e] = (int32_t)u;
+        }
+    c->E = E; c->nnz = nnz;
+    c->h_ev_ptr.assign(ev_ptr, ev_ptr + m + 1);
+    HIPCHK(c->indptr.resize(m + 1)); HIPCHK(c->indices.resize(std::max<int64_t>(nnz, 1)));
+    HIPCHK(c->ev_u.resize(std::max<int64_t>(E, 1))); HIPCHK(c->ev_i.resize(std::max<int64_t>(E, 1))); HIPCHK(c->ev_j.resize(std::max<int64_t>(E, 1)));
+    HIPCHK(hipMemcpyAsync(c->indptr.p, indptr, (m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ev_u.p, evu.data(), E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ev_i.p, ev_i, E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_inter = true;
+    return YUE_OK;
+}
+
+int yue_bpr_replay(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
+                   double lr, double regU, double regI, double *nll_out) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_bpr_replay: no factors uploaded");
+    if (T < 0 || (T > 0 && (!u || !i || !j))) return fail(YUE_ERR_ARG, "yue_bpr_replay: bad triplet arrays");
+    HIPCHK(hipSetDevice(c->device));
+    // Dependency levels: a triplet runs one level after the latest earlier triplet that touches
+    // P[u], Q[i] or Q[j].  Triplets of a level are pairwise row-disjoint, so running a level
+    // concurrently gives exactly the state of the sequential loop (BPR.py:42-58).
+    std::vector<int32_t> lastP((size_t)c->m, 0), lastQ((size_t)c->n, 0), lvl((size_t)T);
+    int32_t nlev = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] >= c->n) return fail(YUE_ERR_ARG, "triplet " + std::to_string(t) + " out of range");
+        if (j[t] < 0) { lvl[(size_t)t] = 0; continue; }
+        if (i[t] == j[t]) return fail(YUE_ERR_ARG, "triplet " + std::to_string(t) + ": i == j");
+        int32_t l = std::max(lastP[(size_t)u[t]], std::max(lastQ[(size_t)i[t]], lastQ[(size_t)j[t]])) + 1;
+        lvl[(size_t)t] = l;
+        lastP[(size_t)u[t]] = lastQ[(size_t)i[t]] = lastQ[(size_t)j[t]] = l;
+        nlev = std::max(nlev, l);
+    }
+    std::vector<int64_t> lptr((size_t)nlev + 2, 0);
+    for (int64_t t = 0; t < T; ++t) if (lvl[(size_t)t] > 0) lptr[(size_t)lvl[(size_t)t] + 1]++;
+    for (int32_t l = 1; l <= nlev + 0; ++l) lptr[(size_t)l + 1] += lptr[(size_t)l];
+    const int64_t Tv = lptr[(size_t)nlev + 1];
+    std::vector<int32_t> pu((size_t)std::max<int64_t>(Tv, 1)), pi((size_t)std::max<int64_t>(Tv, 1)), pj((size_t)std::max<int64_t>(Tv, 1));
+    {
+        std::vector<int64_t> cur(lptr.begin(), lptr.end());
+        for (int64_t t = 0; t < T; ++t) {
+            const int32_t l = lvl[(size_t)t];
+            if (l == 0) continue;
+            const int64_t o = cur[(size_t)l]++;
+            pu[(size_t)o] = u[t]; pi[(size_t)o] = i[t]; pj[(size_t)o] = j[t];
+        }
+    }
+    int rc = upload_triplets(c, pu.data(), pi.data(), pj.data(), Tv);
+    if (rc) return rc;
+    yue::TrainArgs a = make_args(c, lr, regU, regI);
+    a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
+    if ((rc = zero_scalars(c))) return rc;
+    for (int32_t l = 1; l <= nlev; ++l) {
+        const int64_t e0 = lptr[(size_t)l], e1 = lptr[(size_t)l + 1];
+        if (e1 > e0) launch_update<false, true>(c, a, e0, e1, tpw_for(e1 - e0));
+    }
+    HIPCHK(hipGetLastError());
+    return read_scalars(c, nll_out, nullptr, nullptr);
+}
+
+int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, const int64_t *round_ptr, int64_t n_rounds,
+                   double lr, double regU, double regI, double *nll_out) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_bpr_rounds: no factors uploaded");
+    if (!round_ptr || n_rounds < 0) return fail(YUE_ERR_ARG, "yue_bpr_rounds: bad round_ptr");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t T = round_ptr[n_rounds];
+    if (round_ptr[0] != 0) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr[0] must be 0");
+    for (int64_t r = 0; r < n_rounds; ++r) if (round_ptr[r + 1] < round_ptr[r]) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr must be non-decreasing");
+    int rc = upload_triplets(c, u, i, j, T);
+    if (rc) return rc;
+    yue::TrainArgs a = make_args(c, lr, regU, regI);
+    a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
+    if ((rc = zero_scalars(c))) return rc;
+    for (int64_t r = 0; r < n_rounds; ++r) {
+        const int64_t e0 = round_ptr[r], e1 = round_ptr[r + 1];
+        if (e1 <= e0) continue;
+        if ((rc = timed_update<false, false>(c, a, e0, e1, tpw_for(e1 - e0)))) return rc;
+        launch_apply(c, a, e0, e1, 1);
+    }
+    HIPCHK(hipGetLastError());
+    return read_scalars(c, nll_out, nullptr, nullptr);
+}
+
+int yue_sample_negatives(yue_ctx *c, uint64_t seed, uint32_t epoch, int32_t *j_out) {
+    if (!c || !c->have_inter || !j_out) return fail(YUE_ERR_ARG, "yue_sample_negatives: no interactions uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    yue::TrainArgs a = make_args(c, 0, 0, 0);
+    a.seed = seed; a.epoch = epoch;
+    if (c->E > 0) {
+        hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((c->E + 255) / 256)), dim3(256), 0, c->stream, a, c->E);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(j_out, c->ev_j.p, c->E * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
+}
+
+int yue_sumsq(yue_ctx *c, double *sp, double *sq) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_sumsq: no factors uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sumsq_async(c);
+    if (rc) return rc;
+    double h[2];
+    HIPCHK(hipMemcpyAsync(h, c->scal.p + yue::kNllSlots + 1, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (sp) *sp = h[0];
+    if (sq) *sq = h[1];
+    return YUE_OK;
+}
+
+int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_events, double lr, double regU, double regI,
+                  double *nll_out, double *sumsqP_out, double *sumsqQ_out) {
+    if (!c || !c->have_factors || !c->have_inter) return fail(YUE_ERR_ARG, "yue_bpr_epoch: upload factors and interactions first");
+    if (round_events <= 0) return fail(YUE_ERR_ARG, "yue_bpr_epoch: round_events must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    yue::TrainArgs a = make_args(c, lr, regU, regI);
+    a.seed = seed + 0x632BE59BD9B4E019ull * (uint64_t)c->rank;   // independent stream per item shard
+    a.epoch = epoch;
+    int rc = zero_scalars(c);
+    if (rc) return rc;
+    const int64_t E = c->E;
+    if (!c->comm) {
+        const int tpw = tpw_for(round_events);
+        for (int64_t e0 = 0; e0 < E; e0 += round_events) {
+            const int64_t e1 = std::min(E, e0 + round_events);
+            if ((rc = timed_update<true, false>(c, a, e0, e1, tpw))) return rc;
+            launch_apply(c, a, e0, e1, 1);
+        }
+    } else {
+        // Same user blocks on every rank: the block width comes from the job-wide event count.
+        double etot = (double)E;
+        if ((rc = yue_allreduce_f64(c, &etot, 1))) return rc;
+        const double per_user = etot / (double)c->nranks / (double)c->m;
+        const int64_t ub = std::max<int64_t>(1, (int64_t)std::llround((double)round_events / std::max(per_user, 1e-9)));
+        // all-reduce granularity: at least ~8 MB of user-factor differences per collective
+        const int64_t group = std::max<int64_t>(1, (8ll << 20) / std::max<int64_t>(1, ub * c->k * 4));
+        int64_t in_group = 0, g_first = 0;
+        for (int64_t u0 = 0; u0 < c->m; u0 += ub) {
+            const int64_t u1 = std::min(c->m, u0 + ub);
+            const int64_t e0 = c->h_ev_ptr[(size_t)u0], e1 = c->h_ev_ptr[(size_t)u1];
+            if (in_group == 0) g_first = u0;
+            if (e1 > e0) {
+                if ((rc = timed_update<true, false>(c, a, e0, e1, tpw_for(e1 - e0)))) return rc;
+                launch_apply(c, a, e0, e1, 0);
+            }
+            if (++in_group == group || u1 == c->m) {
+                const int64_t first = g_first * c->k, count = (u1 - g_first) * c->k;
+                NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->stream));
+                hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->P.p, c->dP.p, c->dirtyP.p, first, count, c->k);
+                in_group = 0;
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    if ((rc = sumsq_async(c))) return rc;
+    return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
+}
+
+int yue_set_kernel_timing(yue_ctx *c, int stride) {
+    if (!c || stride < 0) return fail(YUE_ERR_ARG, "yue_set_kernel_timing: bad argument");
+    c->timing_stride = stride;
+    c->launch_counter = 0;
+    c->ev_used = 0;
+    return YUE_OK;
+}
+
+int yue_get_kernel_timing(yue_ctx *c, double *total_ms, int64_t *launches, int64_t *triplets) {
+    if (!c) return fail(YUE_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    int64_t trip = 0;
+    for (size_t t = 0; t < c->ev_used; ++t) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_pool[t].first, c->ev_pool[t].second));
+        tot += ms;
+        trip += c->ev_triplets[t];
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)c->ev_used;
+    if (triplets) *triplets = trip;
+    c->ev_used = 0;
+    return YUE_OK;
+}
+
+int yue_get_scan_stats(yue_ctx *c, double *kernel_ms, int64_t *events) {
+    if (!c) return fail(YUE_ERR_ARG, "null context");
+    if (kernel_ms) *kernel_ms = c->scan_ms;
+    if (events) *events = c->scan_events;
+    return YUE_OK;
+}
+
+int yue_scores(yue_ctx *c, int32_t user, float *out_n) {
+    if (!c || !c->have_factors || !out_n) return fail(YUE_ERR_ARG, "yue_scores: no factors uploaded");
+    if (user < 0 || user >= c->m) return fail(YUE_ERR_ARG, "yue_scores: user id out of range");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->s_row.resize(c->n));
+    hipLaunchKernelGGL(yue::k_scores_one, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->P.p + (int64_t)user * c->k, c->Q.p, c->n, c->k, c->s_row.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_n, c->s_row.p, c->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
+}
+
+int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int64_t *mask_indptr, const int32_t *mask_indices,
+                  int32_t *out_ids, float *out_scores) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_topn_scan: no factors uploaded");
+    if (nu < 0 || (nu > 0 && (!users || !out_ids || !out_scores))) return fail(YUE_ERR_ARG, "yue_topn_scan: null argument");
+    if (N < 1 || N > 100) return fail(YUE_ERR_ARG, "yue_topn_scan: N must be in 1..100");
+    if (c->k > 128) return fail(YUE_ERR_ARG, "yue_topn_scan: k > 128 is not supported by the scoring kernel yet");
+    if ((mask_indptr == nullptr) != (mask_indices == nullptr)) return fail(YUE_ERR_ARG, "yue_topn_scan: pass both mask arrays or neither");
+    if (!mask_indptr && !c->have_inter) return fail(YUE_ERR_ARG, "yue_topn_scan: no mask given and no interactions uploaded");
+    if (nu == 0) return YUE_OK;
+    HIPCHK(hipSetDevice(c->device));
+    for (int64_t t = 0; t < nu; ++t) if (users[t] < 0 || users[t] >= c->m) return fail(YUE_ERR_ARG, "yue_topn_scan: user id out of range");
+    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(2));
+    HIPCHK(hipMemcpyAsync(c->s_users.p, users, nu * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    yue::ScanArgs sa{};
+    sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
+    sa.out_ids = c->s_ids.p; sa.out_scores = c->s_scores.p; sa.flags = c->s_flags.p;
+    if (mask_indptr) {
+        const int64_t mnnz = mask_indptr[nu];
+        for (int64_t t = 0; t < nu; ++t) {
+            if (mask_indptr[t + 1] < mask_indptr[t]) return fail(YUE_ERR_ARG, "yue_topn_scan: mask_indptr must be non-decreasing");
+            for (int64_t q = mask_indptr[t]; q < mask_indptr[t + 1]; ++q)
+                if (mask_indices[q] < 0 || mask_indices[q] >= c->n || (q > mask_indptr[t] && mask_indices[q] <= mask_indices[q - 1]))
+                    return fail(YUE_ERR_ARG, "yue_topn_scan: mask rows must be sorted, unique and in range");
+        }
+        HIPCHK(c->s_mask_ptr.resize(nu + 1)); HIPCHK(c->s_mask_idx.resize(std::max<int64_t>(mnnz, 1)));
+        HIPCHK(hipMemcpyAsync(c->s_mask_ptr.p, mask_indptr, (nu + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->s_mask_idx.p, mask_indices, mnnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        sa.mask_ptr = c->s_mask_ptr.p; sa.mask_idx = c->s_mask_idx.p; sa.mask_by_user = 0;
+    } else {
+        sa.mask_ptr = c->indptr.p; sa.mask_idx = c->indices.p; sa.mask_by_user = 1;
+    }
+    HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 2 * sizeof(int32_t), c->stream));
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, c->stream));
+    int rc = yue::launch_scan(sa, c->stream);
+    HIPCHK(hipEventRecord(t1, c->stream));
+    if (rc) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination");
+    HIPCHK(hipGetLastError());
+    int32_t flags[2];
+    HIPCHK(hipMemcpyAsync(out_ids, c->s_ids.p, nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out_scores, c->s_scores.p, nu * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(flags, c->s_flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    c->scan_ms = ms;
+    c->scan_events = flags[1];
+    if (flags[0]) return fail(YUE_ERR_FEW_ITEMS, "a user has fewer than N candidate items (the reference raises IndexError, base/IterativeRecommender.py:126)");
+    return YUE_OK;
+}
+
+int yue_comm_unique_id(void *id128_out) {
+    if (!id128_out) return fail(YUE_ERR_ARG, "yue_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) <= YUE_UNIQUE_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    std::memset(id128_out, 0, YUE_UNIQUE_ID_BYTES);
+    std::memcpy(id128_out, &id, sizeof id);
+    return YUE_OK;
+}
+
+int yue_comm_init(yue_ctx *c, const void *id128, int rank, int nranks) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(YUE_ERR_ARG, "yue_comm_init: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->rank = rank; c->nranks = nranks;
+    return YUE_OK;
+}
+
+int yue_allreduce_f64(yue_ctx *c, double *vals, int count) {
+    if (!c || !vals || count < 1 || count > 8) return fail(YUE_ERR_ARG, "yue_allreduce_f64: bad argument (count 1..8)");
+    if (!c->comm) return YUE_OK;
+    HIPCHK(hipSetDevice(c->device));
+    double *d = c->scal.p + yue::kNllSlots;   // scratch scalars (callers read their results before)
+    HIPCHK(hipMemcpyAsync(d, vals, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, d, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
+}
+
+}  // extern "C"
