@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BPR triplet-updates/s at k=128 (BASELINE.json metric) on N MI355X.
+
+A "step" is one epoch: one pass of the fused sampler + BPR update path over the whole synthetic
+event list (BASELINE config 3: 1M users x 200K items, 50 events/user = 50M triplets), factors and
+interactions resident in HBM before the timed region starts.  For N > 1 the driver launches one
+process per GPU (torch.distributed.run); every rank owns an item shard of the same shape (weak
+scaling), users are replicated, user-factor differences are all-reduced over RCCL inside the
+library; torch.distributed (gloo) is used here only to ship the RCCL id, for the barriers and for
+the max-over-ranks time.
+
+One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the library's stream) and
+`cpu_baseline` (oracle/ timed on one host core, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from yue_amd import synth            # noqa: E402
+from yue_amd._shim import Device, comm_unique_id   # noqa: E402
+
+WORKLOADS = {
+    # name: (users, items per GPU, events per user, k)
+    'c3': (1000000, 200000, 50, 128),
+    'c2': (100000, 50000, 50, 64),
+    'tiny': (20000, 5000, 20, 128),
+}
+LR, REG_U, REG_I = 0.02, 0.01, 0.01
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(k):
+    # 3 rows read + 3 rows written (fp32) + one (u,i) int32 pair per triplet
+    return 24 * k + 8
+
+
+def cpu_baseline(data, P0, Q0, j_first, k, budget_s=15.0):
+    """oracle/bpr_oracle.c sequential loop (the reference's semantics) on one core, bounded sample."""
+    import oracle
+    orc = oracle.Oracle()
+    ev_u = np.repeat(np.arange(data['m'], dtype=np.int32), np.diff(data['ev_ptr']))
+    probe = min(len(j_first), 200000)
+    P, Q = P0.copy(), Q0.copy()
+    t0 = time.perf_counter()
+    orc.bpr_sequential(P, Q, ev_u[:probe], data['ev_i'][:probe], j_first[:probe], LR, REG_U, REG_I)
+    rate = probe / (time.perf_counter() - t0)
+    S = int(min(len(j_first), max(probe, rate * budget_s)))
+    P, Q = P0.copy(), Q0.copy()
+    t0 = time.perf_counter()
+    orc.bpr_sequential(P, Q, ev_u[:S], data['ev_i'][:S], j_first[:S], LR, REG_U, REG_I)
+    dt = time.perf_counter() - t0
+    return {'value': S / dt, 'unit': 'triplets/s', 'cores': 1, 'kind': 'port',
+            'sample': 'first %d triplets of epoch 0 of the same workload, sequential loop of oracle/bpr_oracle.c '
+                      '(restates recommender/cf/BPR.py:42-58), %.1f s on %s' % (S, dt, _cpu_name())}
+
+
+def _cpu_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip() + ' (%d logical cpus)' % os.cpu_count()
+    except OSError:
+        pass
+    return 'unknown cpu'
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--round-events', type=int, default=32768)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    m, n, d, k = WORKLOADS[args.workload]
+    t_setup = time.perf_counter()
+    data = synth.make_arrays(m, n, d, seed=20260001 + 7919 * rank)     # this rank's item shard
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    if rank != 0:
+        Q0 = synth.init_factors(1, n, k, 20260002 + rank)[1]
+    E = int(data['ev_ptr'][-1])
+
+    dev = Device(local_rank, raise_errors=True)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    if world > 1:
+        import torch
+        ident = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        dev.comm_init(ident[0], rank, world)
+    setup_s = time.perf_counter() - t_setup
+
+    seed = 20260003
+    epoch = 0
+    for _ in range(args.warmup):
+        dev.bpr_epoch(seed, epoch, args.round_events, LR, REG_U, REG_I)
+        epoch += 1
+    n_rounds = (E + args.round_events - 1) // args.round_events
+    dev.set_kernel_timing(max(1, n_rounds // 128))      # ~128 bracketed launches per epoch
+
+    def barrier():
+        dev.sync()
+        if dist is not None:
+            dist.barrier()
+        dev.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    nll = 0.0
+    for _ in range(args.steps):
+        nll, sp, sq = dev.bpr_epoch(seed, epoch, args.round_events, LR, REG_U, REG_I)
+        epoch += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    k_ms, k_launches, k_triplets = dev.get_kernel_timing()
+    dev.set_kernel_timing(0)
+    if not np.isfinite(nll):
+        sys.exit('loss is not finite')
+
+    if rank == 0:
+        total = float(E) * world * args.steps
+        value = total / dt
+        ab = algorithmic_bytes(k)
+        achieved = ab * k_triplets / (k_ms * 1e-3) if k_ms > 0 else 0.0
+        out = {
+            'metric': 'BPR triplet-updates/sec at k=%d' % k, 'value': value, 'unit': 'triplets/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: BPR k=%d, %d users x %d items per GPU, %d events/user (%d triplets per epoch per GPU), '
+                                   'fused counter-based sampler, S-round W=%d events, lr=%g regU=regI=%g'
+                                   % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),
+                       'round_events': args.round_events, 'parallelism': 'items sharded x%d, users replicated' % world,
+                       'setup_s': round(setup_s, 1), 'final_nll_per_triplet': nll / E},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_bpr_update<KR=%d,SAMPLE,accumulate>' % (1 if k <= 32 else 2 if k <= 64 else 4 if k <= 128 else 8),
+                         'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
+                         'algorithmic_bytes_per_triplet': ab, 'launches_timed': k_launches,
+                         'avg_launch_ms': (k_ms / k_launches) if k_launches else None,
+                         'triplets_per_launch': (k_triplets / k_launches) if k_launches else None,
+                         'traffic': None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            j0 = dev.sample_negatives(seed, 0)
+            out['cpu_baseline'] = cpu_baseline(data, P0, Q0, j0, k)
+        print(json.dumps(out))
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

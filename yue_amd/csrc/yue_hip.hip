@@ -236,7 +236,7 @@ int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64
     if (m <= 0 || n <= 0 || k <= 0 || k > 256) return fail(YUE_ERR_ARG, "yue_set_factors: need m,n > 0 and 1 <= k <= 256");
     if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: ids must fit int32");
     HIPCHK(hipSetDevice(c->device));
-    if (c->have_inter && (m != c->m)) return fail(YUE_ERR_ARG, "yue_set_factors: m differs from the uploaded interactions");
+    if (c->have_inter && (m != c->m || n != c->n)) c->have_inter = false;   // new shape: interactions must be uploaded again
     c->m = m; c->n = n; c->k = k;
     HIPCHK(c->P.resize(m * k)); HIPCHK(c->Q.resize(n * k));
     HIPCHK(c->dP.resize(m * k)); HIPCHK(c->dQ.resize(n * k));
