@@ -1,0 +1,69 @@
+"""GPU, end to end through the reference's plugin surface: BPR.conf on the 1K x 1K synthetic log
+(BASELINE config 1), driven exactly as tools/make_goldens.py drives the reference, compared with
+what the reference produced: factors (1e-5 rel), the printed iteration lines, integer ranking
+lists, the lists file, the measure strings."""
+import glob
+import os
+import random
+
+import numpy as np
+import pytest
+
+from test_host_golden import _c1_conf, _load
+from util import gj, gz, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260002
+
+
+def _trained(tmp_path, capsys, iters=1, topn='5,10'):
+    from yue_amd.recommender.cf.BPR import BPR
+    conf = _c1_conf(tmp_path, 10, iters, topn)
+    rec = BPR(conf, _load(conf), [])
+    rec.readConfiguration()
+    random.seed(SEED)
+    np.random.seed(SEED)
+    rec.initModel()
+    capsys.readouterr()
+    rec.buildModel()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if 'iteration' in ln]
+    return rec, lines
+
+
+@pytest.mark.parametrize('iters,tag', [(1, 'c1_k10_e1'), (5, 'c1_k10_e5')])
+def test_buildmodel_matches_reference(tmp_path, capsys, iters, tag):
+    rec, lines = _trained(tmp_path, capsys, iters)
+    z, meta = gz('g4_%s.npz' % tag), gj('g4_%s.json' % tag)
+    assert lines == meta['lines']                       # loss, delta and bold-driver learning rate
+    assert rel_err(rec.P, z['P']) < 1e-5 and rel_err(rec.Q, z['Q']) < 1e-5
+    assert abs(rec.lRate - float(z['lRate'])) < 1e-12
+    assert type(rec.loss).__name__ == meta['loss_type']
+
+
+@pytest.mark.parametrize('topn,tag', [('5,10', 'c1_top10'), ('10,20', 'c1_top20')])
+def test_evalranking_matches_reference(tmp_path, capsys, topn, tag):
+    rec, _ = _trained(tmp_path, capsys, 1, topn)
+    g, gjs = gz('g5_%s.npz' % tag), gj('g5_%s.json' % tag)
+    rec.evalRanking()
+    assert rec.measure == gjs['measure']
+    lists_file = [f for f in glob.glob(str(tmp_path / 'results' / '*items*.txt'))][0]
+    assert open(lists_file).read() == gjs['lists_txt']
+    users = list(rec.data.testSet.keys())
+    for t in range(16):
+        s = rec.predict(users[t])
+        assert np.abs(s - g['predict16'][t]).max() <= 4e-7 * np.abs(g['predict16'][t]).max()
+    if tag == 'c1_top10':
+        assert rec.ranking_performance() == gj('g6_ranking_performance.json')['measure']
+
+
+def test_execute_lifecycle_and_epoch_mode(tmp_path, capsys):
+    from yue_amd.yue import Yue
+    conf = _c1_conf(tmp_path, 10, 3, '5,10')
+    conf.config['bpr.hip'] = '-mode epoch -round 2048 -seed 5 -gpu 0'
+    Yue(conf).execute()
+    out = capsys.readouterr().out
+    assert 'BPR [1] iteration 3' in out and 'Top 10' in out
+    assert glob.glob(str(tmp_path / 'results' / '*measure*.txt'))
+    losses = [float(ln.split('loss = ')[1].split(',')[0]) for ln in out.splitlines() if 'iteration' in ln]
+    assert losses[2] < losses[1] < losses[0]

@@ -1,0 +1,30 @@
+"""Menu front end (reference main.py:7-80).  `python -m yue_amd.main` from the repository root."""
+import os
+import time
+
+from .tool.config import Config
+from .yue import Yue
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MENU = {'1': 'BPR'}
+
+
+def main():
+    print('=' * 80)
+    print('   Yue: Library for Music Recommendation (MI355X BPR path).   ')
+    print('=' * 80)
+    print('CF-based Recommenders:')
+    print('1. BPR')
+    print('=' * 80)
+    order = input('Please enter the num of the algorithm to run it:')
+    start = time.time()
+    if order not in MENU:
+        print('Error num!')
+        exit(-1)
+    conf = Config(os.path.join(_HERE, 'config', MENU[order] + '.conf'))
+    Yue(conf).execute()
+    print("Run time: %f s" % (time.time() - start))
+
+
+if __name__ == '__main__':
+    main()

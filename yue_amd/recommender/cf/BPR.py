@@ -1,0 +1,85 @@
+#coding:utf8
+"""BPR (Rendle et al.) behind the reference's plugin hooks, trained on one MI355X.
+
+Replaces the NumPy epoch loop of the reference (recommender/cf/BPR.py:31-62).  The optional
+config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unchanged):
+
+  bpr.hip=-mode replay                  (default) negatives drawn on the host exactly as the
+                                        reference draws them (random.choice + rejection,
+                                        BPR.py:46-48, so a seeded `random` gives the same stream);
+                                        the device applies the triplets with exact sequential
+                                        semantics (yue_bpr_replay).  Same results as the reference.
+  bpr.hip=-mode epoch -round 32768 -seed 1
+                                        throughput mode: counter-based sampler fused into the
+                                        update kernel, S-round semantics.
+  -gpu N                                HIP device ordinal.
+"""
+from random import choice
+
+import numpy as np
+
+from ...base.IterativeRecommender import IterativeRecommender
+from ...tool.config import LineConfig
+
+
+class BPR(IterativeRecommender):
+
+    def __init__(self, conf, trainingSet=None, testSet=None, fold='[1]'):
+        super(BPR, self).__init__(conf, trainingSet, testSet, fold)
+
+    def initModel(self):
+        super(BPR, self).initModel()
+        self.m = self.data.getSize('user')
+        self.n = self.data.getSize(self.recType)
+        self.train_size = len(self.data.trainingData)
+
+    def _options(self):
+        opts = {'-mode': 'replay', '-round': '32768', '-seed': '1'}
+        if self.config.contains('bpr.hip'):
+            given = LineConfig(self.config['bpr.hip'])
+            for key in opts:
+                if given.contains(key):
+                    opts[key] = given[key]
+        return opts
+
+    def _draw_negatives(self, itemList, listened_names):
+        """BPR.py:42-49: one rejection-sampled negative per training event, reference order."""
+        item_ids = self.data.name2id[self.recType]
+        out = []
+        for user in self.data.userRecord:
+            mine = listened_names[user]
+            for _ in self.data.userRecord[user]:
+                item_j = choice(itemList)
+                while item_j in mine:
+                    item_j = choice(itemList)
+                out.append(item_ids[item_j])
+        return np.asarray(out, np.int32)
+
+    def buildModel(self):
+        opts = self._options()
+        self._sync_factors_to_device()
+        dev, arr = self.dev, self._arrays
+        ev_u = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(arr['ev_ptr']))
+        listened_names = {user: {ev[self.recType] for ev in events} for user, events in self.data.userRecord.items()}
+        itemList = list(self.data.name2id[self.recType].keys())
+        print('training...')
+        iteration = 0
+        while iteration < self.maxIter:
+            if opts['-mode'] == 'replay':
+                j = self._draw_negatives(itemList, listened_names)
+                nll = dev.bpr_replay(ev_u, arr['ev_i'], j, self.lRate, self.regU, self.regI)
+                sumP, sumQ = dev.sumsq()
+            else:
+                nll, sumP, sumQ = dev.bpr_epoch(int(opts['-seed']), iteration, int(opts['-round']), self.lRate, self.regU, self.regI)
+            # BPR.py:58-59.  Under NumPy 2 `regU * (P*P).sum()` is a float32 and turns the loss into
+            # a float32; the same promotion is applied here so the printed line matches.
+            self.loss = nll + (self.regU * np.float32(sumP) + self.regI * np.float32(sumQ))
+            iteration += 1
+            if self.isConverged(iteration):
+                break
+        dev.get_factors(self.P, self.Q)          # state contract: trained factors back on the host
+        self._device_factors_current = True
+
+    def predict(self, u):
+        'invoked to rank all the items for the user'
+        return super(BPR, self).predict(u)
