@@ -6,8 +6,8 @@ event list (BASELINE config 3: 1M users x 200K items, 50 events/user = 50M tripl
 interactions resident in HBM before the timed region starts.  For N > 1 the driver launches one
 process per GPU (torch.distributed.run); every rank owns an item shard of the same shape (weak
 scaling), users are replicated, user-factor differences are all-reduced over RCCL inside the
-library; torch.distributed (gloo) is used here only to ship the RCCL id, for the barriers and for
-the max-over-ranks time.
+library; torch.distributed (gloo, yue_amd/dist.py) only ships the RCCL id, runs the barriers and
+takes the max-over-ranks time.
 
 One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the library's stream) and
 `cpu_baseline` (oracle/ timed on one host core, N=1 only).
@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from yue_amd import synth            # noqa: E402
-from yue_amd._shim import Device, comm_unique_id   # noqa: E402
+from yue_amd._shim import Device   # noqa: E402
+from yue_amd.dist import ControlPlane, attach_device   # noqa: E402
 
 WORKLOADS = {
     # name: (users, items per GPU, events per user, k)
@@ -81,19 +82,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    cp = ControlPlane()
+    rank, world, local_rank = cp.rank, cp.world, cp.local_rank
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
         args.gpus = world
-
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
 
     m, n, d, k = WORKLOADS[args.workload]
     t_setup = time.perf_counter()
@@ -106,11 +100,7 @@ def main():
     dev = Device(local_rank, raise_errors=True)
     dev.set_factors(P0, Q0)
     dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
-    if world > 1:
-        import torch
-        ident = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        dev.comm_init(ident[0], rank, world)
+    attach_device(dev, cp)
     setup_s = time.perf_counter() - t_setup
 
     seed = 20260003
@@ -123,8 +113,7 @@ def main():
 
     def barrier():
         dev.sync()
-        if dist is not None:
-            dist.barrier()
+        cp.barrier()
         dev.sync()
 
     barrier()
@@ -135,11 +124,7 @@ def main():
         epoch += 1
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt = cp.reduce_max(dt)
     k_ms, k_launches, k_triplets = dev.get_kernel_timing()
     dev.set_kernel_timing(0)
     if not np.isfinite(nll):
@@ -171,8 +156,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(data, P0, Q0, j0, k)
         print(json.dumps(out))
     dev.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    cp.close()
 
 
 if __name__ == '__main__':

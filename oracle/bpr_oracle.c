@@ -267,6 +267,30 @@ double orc_bpr_rounds(float *P, float *Q, int64_t m, int64_t n, int k,
     return nll;
 }
 
+/*
+ * One round's summed differences WITHOUT applying them (factors untouched): what one rank
+ * contributes for a user block when items are sharded over several GPUs (multi-GPU).
+ * dP[m*k] and dQ[n*k] must be zero on entry.  Returns the round's sum of -log(s).
+ */
+double orc_bpr_round_deltas(const float *P, const float *Q, int k,
+                            const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
+                            double lr, double regU, double regI, float *dP, float *dQ) {
+    double nll = 0.0;
+    for (int64_t t = 0; t < T; t++) {
+        if (j[t] < 0) continue;
+        const float *p = P + (int64_t)u[t] * k, *qi = Q + (int64_t)i[t] * k, *qj = Q + (int64_t)j[t] * k;
+        coef_t cf = coef(p, qi, qj, k, lr, regU, regI);
+        float *dp = dP + (int64_t)u[t] * k, *dqi = dQ + (int64_t)i[t] * k, *dqj = dQ + (int64_t)j[t] * k;
+        for (int e = 0; e < k; e++) {
+            float p2, qi2, qj2;
+            upd1(p[e], qi[e], qj[e], cf, &p2, &qi2, &qj2);
+            dp[e] += p2 - p[e]; dqi[e] += qi2 - qi[e]; dqj[e] += qj2 - qj[e];
+        }
+        nll += -log(cf.s);
+    }
+    return nll;
+}
+
 /* BPR.py:59 -- sums of squares; products in fp32 as NumPy forms P*P, accumulated in double */
 double orc_sumsq(const float *X, int64_t count) {
     double s = 0.0;

@@ -32,6 +32,7 @@ class Oracle(object):
         L.orc_bpr_sequential.restype = C.c_double
         L.orc_bpr_rounds.restype = C.c_double
         L.orc_sumsq.restype = C.c_double
+        L.orc_bpr_round_deltas.restype = C.c_double
         L.orc_topn_scan.restype = C.c_int
 
     # -- samplers -------------------------------------------------------------
@@ -72,6 +73,16 @@ class Oracle(object):
         return self.lib.orc_bpr_rounds(_p(P, C.c_float), _p(Q, C.c_float), C.c_int64(P.shape[0]), C.c_int64(Q.shape[0]), C.c_int(P.shape[1]),
                                        _p(u, C.c_int32), _p(i, C.c_int32), _p(j, C.c_int32), _p(rp, C.c_int64), C.c_int64(len(rp) - 1),
                                        C.c_double(lr), C.c_double(regU), C.c_double(regI))
+
+    def bpr_round_deltas(self, P, Q, u, i, j, lr, regU, regI):
+        """(nll, dP, dQ): summed per-row differences of one round, factors untouched."""
+        u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
+        dP = np.zeros_like(P)
+        dQ = np.zeros_like(Q)
+        nll = self.lib.orc_bpr_round_deltas(_p(P, C.c_float), _p(Q, C.c_float), C.c_int(P.shape[1]), _p(u, C.c_int32), _p(i, C.c_int32),
+                                            _p(j, C.c_int32), C.c_int64(len(u)), C.c_double(lr), C.c_double(regU), C.c_double(regI),
+                                            _p(dP, C.c_float), _p(dQ, C.c_float))
+        return nll, dP, dQ
 
     def sumsq(self, X):
         X = np.ascontiguousarray(X, np.float32)
