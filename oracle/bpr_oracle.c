@@ -164,21 +164,22 @@ void orc_sample_counter(uint64_t seed, uint32_t epoch, const int32_t *ev_u, int6
 /* ------------------------------------------------------------------------- */
 /*
  * Summation order of the k-length dot.  The reference calls BLAS sdot, whose order is
- * not pinned; we fix one: 32 strided partials (element 32r+l goes to
+ * not pinned; we fix one: 64 strided partials (element 64r+l goes to
  * partial l, r ascending, product and sum rounded separately) followed by a butterfly
- * (offsets 16,8,4,2,1).  The HIP kernel uses the same order, so replay is comparable
- * bit for bit; against the reference's BLAS result it agrees to fp32 rounding.
+ * with partner l^1, l^2, l^4, l^8, l^16, l^32.  The HIP kernels use the same order, so
+ * replay is comparable bit for bit; against the reference's BLAS result it agrees to
+ * fp32 rounding.
  */
-static float dot32(const float *a, const float *b, int k) {
-    float part[32];
-    for (int l = 0; l < 32; l++) {
+static float dot64(const float *a, const float *b, int k) {
+    float part[64];
+    for (int l = 0; l < 64; l++) {
         float acc = 0.0f;
-        for (int e = l; e < k; e += 32) { float pr = a[e] * b[e]; acc = acc + pr; }
+        for (int e = l; e < k; e += 64) { float pr = a[e] * b[e]; acc = acc + pr; }
         part[l] = acc;
     }
-    for (int off = 16; off >= 1; off >>= 1) {
-        float nxt[32];
-        for (int l = 0; l < 32; l++) nxt[l] = part[l] + part[l ^ off];
+    for (int off = 1; off <= 32; off <<= 1) {
+        float nxt[64];
+        for (int l = 0; l < 64; l++) nxt[l] = part[l] + part[l ^ off];
         memcpy(part, nxt, sizeof part);
     }
     return part[0];
@@ -189,7 +190,7 @@ typedef struct { float c, ru, ri; double s; } coef_t;
 /* BPR.py:50 + qmath.py:115-116: s in double on the fp32 margin; coefficient rounded to fp32 once */
 static coef_t coef(const float *p, const float *qi, const float *qj, int k, double lr, double regU, double regI) {
     coef_t r;
-    float x = dot32(p, qi, k) - dot32(p, qj, k);
+    float x = dot64(p, qi, k) - dot64(p, qj, k);
     r.s = 1.0 / (1.0 + exp(-(double)x));
     r.c = (float)(lr * (1.0 - r.s));
     r.ru = (float)(lr * regU);

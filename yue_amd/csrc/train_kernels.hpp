@@ -1,11 +1,10 @@
 // BPR training kernels for gfx950 (CDNA4).  Wave = 64 lanes.
 //
-// Layout of one triplet (u, i, j) inside a wave: lanes 0-31 own the positive row Q[i],
-// lanes 32-63 the negative row Q[j]; element 32*r + (lane & 31) sits in register r of its
-// half, so every load / atomic wave-instruction touches two contiguous 128-byte segments
-// (one per row) -- the shape that runs at the full float-atomic rate on MI355X.  P[u] is held
-// by both halves.  The k-length dots are reduced with a 32-lane butterfly per half, which is
-// the summation order oracle/bpr_oracle.c:dot32 restates.
+// Layout of one triplet (u, i, j) inside a wave: lane l holds elements 64*r + l of P[u], Q[i]
+// and Q[j], so every load / store / atomic wave-instruction covers 256 contiguous bytes of one
+// row -- the shape that runs at the full float-atomic and plain-store rates on MI355X.  The
+// k-length dots are reduced with a 64-lane butterfly (DPP-fused adds), which is the summation
+// order oracle/bpr_oracle.c:dot64 restates.
 //
 // Arithmetic follows recommender/cf/BPR.py:50-57 of the reference: margin in fp32, sigmoid in
 // double on it (tool/qmath.py:115-116), coefficient rounded to fp32 once, every multiply and
@@ -21,7 +20,7 @@ constexpr int kMaxAttempts = 64;
 
 struct TrainArgs {
     float *P, *Q, *dP, *dQ;
-    uint32_t *dirtyP, *dirtyQ;
+    uint32_t *dirtyP;
     const int32_t *ev_u, *ev_i;
     int32_t *ev_j;
     const int64_t *indptr;
@@ -34,6 +33,16 @@ struct TrainArgs {
     uint64_t seed;
     uint32_t epoch;
     int32_t neg_lo, neg_range;
+};
+
+// One round of the S-round schedule.
+struct RoundArgs {
+    int64_t e_begin, e_end;      // events updated by this launch
+    int64_t n_begin, n_end;      // events of the NEXT round: negatives drawn and row touches counted here
+    uint32_t *cnt_cur;           // touches per item row in [e_begin, e_end)   (filled by the previous launch)
+    uint32_t *cnt_next;          // touches per item row in [n_begin, n_end)
+    int sample_next;             // 1: draw ev_j for the next round (fused sampler); 0: ev_j is given
+    int prep_blocks;             // blocks [0, prep_blocks) run the sample+count role
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -73,141 +82,288 @@ __global__ void __launch_bounds__(256) k_sample(TrainArgs a, int64_t E) {
     if (e < E) a.ev_j[e] = sample_negative(a, a.ev_u[e], e);
 }
 
-// One wave walks `tpw` consecutive events [base, base+cnt).
-//   SAMPLE: draw j in-kernel (fused sampler) and record it in ev_j; else read ev_j.
-//   DIRECT: the launch is conflict-free (a dependency level): write the updated rows in place.
-//   else  : S-round -- add (new - old) into dP/dQ, factors stay at the round-start snapshot.
-template <int KR, bool SAMPLE, bool DIRECT>
-__global__ void __launch_bounds__(256) k_bpr_update(TrainArgs a, int64_t e_begin, int64_t e_end, int tpw) {
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 64 lanes in the canonical order of oracle/bpr_oracle.c:dot64 -- butterfly with
+// partner lane^1, ^2, ^4, ^8, ^16, then (lanes 0-31) + (lanes 32-63).  The first four steps are
+// DPP-fused adds (quad_perm, quad_perm, row_half_mirror, row_mirror: same operands as the xor
+// partners because the value is already constant over the smaller groups), xor 16 is a ds_swizzle.
+// Returns the total as a wave-uniform value.
+__device__ __forceinline__ float wave_sum(float v) {
+    v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v);      // row_half_mirror
+    v = v + dpp_mov<0x140>(v);      // row_mirror
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // swap 16
+    return rdlane(v, 0) + rdlane(v, 32);
+}
+
+// Reference triplet update on one element (BPR.py:51-57), every product and sum rounded separately.
+struct Elem { float p2, qi2, qj2; };
+__device__ __forceinline__ Elem bpr_elem(float p, float qi, float qj, float c, float ru, float ri) {
+    const float d = qi - qj;
+    const float td = c * d;
+    const float p1 = p + td;            // :51
+    const float tq = c * p1;
+    const float qi1 = qi + tq;          // :52 (updated P[u])
+    const float qj1 = qj - tq;          // :53
+    const float rp = ru * p1;
+    const float ra = ri * qi1;
+    const float rb = ri * qj1;
+    Elem o;
+    o.p2 = p1 - rp;                     // :55
+    o.qi2 = qi1 - ra;                   // :56
+    o.qj2 = qj1 - rb;                   // :57
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave layout: lane l holds elements 64*r + l (r < KR) of P[u], Q[i] and Q[j]; every load, store
+// and atomic wave-instruction covers 256 contiguous bytes of one row.
+//
+// Exact replay: one launch = one dependency level (pairwise row-disjoint triplets), rows are
+// rewritten in place.  One wave walks `tpw` consecutive triplets of the level.
+// ------------------------------------------------------------------------------------------
+template <int KR>
+__global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin, int64_t e_end, int tpw) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t base = e_begin + wave * tpw;
     if (base >= e_end) return;
     const int cnt = (int)((e_end - base) < (int64_t)tpw ? (e_end - base) : (int64_t)tpw);
-
-    int u = -1, i = 0, j = -1;
-    if (lane < cnt) {
-        const int64_t e = base + lane;
-        u = a.ev_u[e];
-        i = a.ev_i[e];
-        if (SAMPLE) { j = sample_negative(a, u, e); a.ev_j[e] = j; }
-        else j = a.ev_j[e];
-    }
-
-    const int hl = lane & 31;
-    const bool hi = lane >= 32;
+    int u = 0, i = 0, j = 0;
+    if (lane < cnt) { u = a.ev_u[base + lane]; i = a.ev_i[base + lane]; j = a.ev_j[base + lane]; }
     const int k = a.k;
-    float p[KR], dp[KR];
-    int cur_u = -1;
     double nll = 0.0;
-
     for (int t = 0; t < cnt; ++t) {
-        const int tu = __builtin_amdgcn_readlane(u, t);
-        const int ti = __builtin_amdgcn_readlane(i, t);
-        const int tj = __builtin_amdgcn_readlane(j, t);
-        if (tj < 0) continue;                       // sampler gave up: triplet skipped (oracle does the same)
-        if (DIRECT || tu != cur_u) {
-            if (!DIRECT && cur_u >= 0 && !hi) {
+        const int64_t tu = __builtin_amdgcn_readlane(u, t);
+        const int64_t ti = __builtin_amdgcn_readlane(i, t);
+        const int64_t tj = __builtin_amdgcn_readlane(j, t);
+        float p[KR], qi[KR], qj[KR];
 #pragma unroll
-                for (int r = 0; r < KR; ++r) { const int e = 32 * r + hl; if (e < k) atomicAdd(a.dP + (int64_t)cur_u * k + e, dp[r]); }
-                if (lane == 0) a.dirtyP[cur_u] = 1u;
-            }
-#pragma unroll
-            for (int r = 0; r < KR; ++r) { const int e = 32 * r + hl; p[r] = e < k ? a.P[(int64_t)tu * k + e] : 0.0f; dp[r] = 0.0f; }
-            cur_u = tu;
+        for (int r = 0; r < KR; ++r) {
+            const int e = 64 * r + lane;
+            p[r] = e < k ? a.P[tu * k + e] : 0.0f;
+            qi[r] = e < k ? a.Q[ti * k + e] : 0.0f;
+            qj[r] = e < k ? a.Q[tj * k + e] : 0.0f;
         }
-        const int64_t row = hi ? tj : ti;
-        float q[KR];
+        float ai = 0.0f, aj = 0.0f;
 #pragma unroll
-        for (int r = 0; r < KR; ++r) { const int e = 32 * r + hl; q[r] = e < k ? a.Q[row * k + e] : 0.0f; }
-
-        float acc = 0.0f;
-#pragma unroll
-        for (int r = 0; r < KR; ++r) { const float pr = p[r] * q[r]; acc = acc + pr; }
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-        const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 0));
-        const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 32));
-        const float x = di - dj;                                   // BPR.py:50, fp32 margin
+        for (int r = 0; r < KR; ++r) { const float a1 = p[r] * qi[r]; ai = ai + a1; const float a2 = p[r] * qj[r]; aj = aj + a2; }
+        const float x = wave_sum(ai) - wave_sum(aj);               // BPR.py:50, fp32 margin
         const double s = 1.0 / (1.0 + exp(-(double)x));            // qmath.py:115-116
         const float c = (float)(a.lr * (1.0 - s));
         nll += -log(s);                                            // BPR.py:58
-
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
-            const int e = 32 * r + hl;
-            const float other = __shfl_xor(q[r], 32);
-            const float qi = hi ? other : q[r];
-            const float qj = hi ? q[r] : other;
-            const float d = qi - qj;
-            const float td = c * d;
-            const float p1 = p[r] + td;                            // :51
-            const float tq = c * p1;
-            const float q1 = hi ? (q[r] - tq) : (q[r] + tq);       // :53 / :52 (updated P[u])
-            const float rq = a.ri * q1;
-            const float q2 = q1 - rq;                              // :56 / :57
-            const float rp = a.ru * p1;
-            const float p2 = p1 - rp;                              // :55
-            if (e < k) {
-                if (DIRECT) {
-                    a.Q[row * k + e] = q2;
-                    if (!hi) a.P[(int64_t)tu * k + e] = p2;
-                } else {
-                    atomicAdd(a.dQ + row * k + e, q2 - q[r]);
-                    dp[r] += p2 - p[r];
-                }
+            const int e = 64 * r + lane;
+            const Elem o = bpr_elem(p[r], qi[r], qj[r], c, a.ru, a.ri);
+            if (e < k) { a.P[tu * k + e] = o.p2; a.Q[ti * k + e] = o.qi2; a.Q[tj * k + e] = o.qj2; }
+        }
+    }
+    if (lane == 0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);
+}
+
+// ------------------------------------------------------------------------------------------
+// S-round launch.  Blocks [0, prep_blocks) prepare the NEXT round (one thread per event: draw the
+// negative, count the two item-row touches).  The other blocks update THIS round: one wave takes
+// TPW consecutive events, requests all their rows up front (straight-line code: the compiler's
+// counted waits keep every gather in flight), evaluates the TPW sigmoids in one double-precision
+// pass (lane t holds triplet t), then writes:
+//   * an item row touched exactly once in the round (cnt == 1): the new row, in place, plain
+//     stores -- nobody else reads or writes it this round;
+//   * a contended row: (new - old) added into dQ with float atomics; k_apply_round adds dQ once.
+// P[u] differences are summed in registers over a run of equal users and flushed into dP.
+// ------------------------------------------------------------------------------------------
+// Raw buffer access: one 128-bit descriptor per matrix in SGPRs, the row's byte offset in an SGPR
+// (soffset), the lane's element offset in one VGPR (voffset) -- no per-access address arithmetic in
+// the vector ALU.  A lane whose element index is >= k gets a voffset beyond num_records: the
+// hardware returns 0 for its loads and drops its stores and atomics.
+#define YUE_BLOAD(rs, vo, so) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rs), (vo), (so), 0))
+#define YUE_BSTORE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 0)
+#define YUE_BATOMIC(val, rs, vo, so) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((val), (rs), (vo), (so), 0)
+constexpr unsigned kOobOffset = 0x80000000u;
+constexpr int kRsrcFlags = 0x00020000;
+
+template <int KR, int TPW>
+__global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < ra.prep_blocks) {
+        const int64_t e = ra.n_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e < ra.n_end) {
+            const int32_t i = a.ev_i[e];
+            int32_t j;
+            if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
+            else j = a.ev_j[e];
+            if (j >= 0) { atomicAdd(ra.cnt_next + i, 1u); atomicAdd(ra.cnt_next + j, 1u); }
+        }
+        return;
+    }
+    const int64_t wave = (int64_t)(blockIdx.x - ra.prep_blocks) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t base = ra.e_begin + wave * TPW;
+    if (base >= ra.e_end) return;
+
+    int u = 0, i = 0, j = -1;
+    uint32_t ci = 0, cj = 0;
+    if (lane < TPW && base + lane < ra.e_end) {
+        u = a.ev_u[base + lane];
+        i = a.ev_i[base + lane];
+        j = a.ev_j[base + lane];
+        if (j >= 0) { ci = ra.cnt_cur[i]; cj = ra.cnt_cur[j]; }
+    }
+    const unsigned k = (unsigned)a.k;
+    const unsigned row_bytes = k * 4u;
+    unsigned vo[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; vo[r] = e < k ? e * 4u : kOobOffset; }
+
+    // users of one batch are neighbours: P / dP are addressed relative to the batch's first user
+    const unsigned u0 = (unsigned)__builtin_amdgcn_readlane(u, 0);
+    const uint64_t qbytes = (uint64_t)a.n * row_bytes, pbytes = (uint64_t)(a.m - u0) * row_bytes;
+    const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
+    const int prec = (int)(pbytes < 0x7fffffffull ? pbytes : 0x7fffffffull);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(a.Q, 0, qrec, kRsrcFlags);
+    const auto rsdQ = __builtin_amdgcn_make_buffer_rsrc(a.dQ, 0, qrec, kRsrcFlags);
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.P + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
+    const auto rsdP = __builtin_amdgcn_make_buffer_rsrc(a.dP + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
+
+    unsigned oi[TPW], oj[TPW], ou[TPW], ru_[TPW], ri_[TPW], rj_[TPW];
+    bool ok[TPW];
+    float qi[TPW][KR], qj[TPW][KR], p[TPW][KR];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        ru_[t] = (unsigned)__builtin_amdgcn_readlane(u, t);
+        ri_[t] = (unsigned)__builtin_amdgcn_readlane(i, t);
+        const int tj = __builtin_amdgcn_readlane(j, t);
+        ok[t] = tj >= 0;                                 // no event / sampler gave up: nothing is written
+        rj_[t] = ok[t] ? (unsigned)tj : 0u;
+        oi[t] = ri_[t] * row_bytes; oj[t] = rj_[t] * row_bytes;
+        ou[t] = (ok[t] ? ru_[t] - u0 : 0u) * row_bytes;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) { qi[t][r] = YUE_BLOAD(rsQ, vo[r], oi[t]); qj[t][r] = YUE_BLOAD(rsQ, vo[r], oj[t]); }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) p[t][r] = YUE_BLOAD(rsP, vo[r], ou[t]);
+
+    float xs = 0.0f;                                     // lane t will hold the margin of triplet t
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        float ai = 0.0f, aj = 0.0f;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const float a1 = p[t][r] * qi[t][r]; ai = ai + a1;
+            const float a2 = p[t][r] * qj[t][r]; aj = aj + a2;
+        }
+        const float x = wave_sum(ai) - wave_sum(aj);               // BPR.py:50, fp32 margin
+        xs = lane == t ? x : xs;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double s = 1.0 / (1.0 + exp(-(double)xs));               // qmath.py:115-116
+    const float cs = (float)(a.lr * (1.0 - s));
+    double nll = (lane < TPW && j >= 0) ? -log(s) : 0.0;           // BPR.py:58
+    __builtin_amdgcn_sched_barrier(0);
+
+    float dp[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
+    bool run_ok = false;                                 // some triplet of the current user run wrote
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const float c = rdlane(cs, t);
+        const bool uniq_i = __builtin_amdgcn_readlane(ci, t) == 1u;
+        const bool uniq_j = __builtin_amdgcn_readlane(cj, t) == 1u;
+        if (ok[t]) {                                     // wave-uniform
+            run_ok = true;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const Elem o = bpr_elem(p[t][r], qi[t][r], qj[t][r], c, a.ru, a.ri);
+                if (uniq_i) YUE_BSTORE(o.qi2, rsQ, vo[r], oi[t]); else YUE_BATOMIC(o.qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
+                if (uniq_j) YUE_BSTORE(o.qj2, rsQ, vo[r], oj[t]); else YUE_BATOMIC(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
+                dp[r] += o.p2 - p[t][r];
+            }
+            if (lane == 0) {                             // sole toucher: reset the count here
+                if (uniq_i) ra.cnt_cur[ri_[t]] = 0u;
+                if (uniq_j) ra.cnt_cur[rj_[t]] = 0u;
             }
         }
-        if (!DIRECT && hl == 0) a.dirtyQ[row] = 1u;
-    }
-    if (!DIRECT && cur_u >= 0 && !hi) {
+        // end of a run of equal users (or of the batch): flush the summed P[u] differences
+        const bool last = (t == TPW - 1) || ru_[t + 1 < TPW ? t + 1 : t] != ru_[t];
+        if (last) {
+            if (run_ok) {
 #pragma unroll
-        for (int r = 0; r < KR; ++r) { const int e = 32 * r + hl; if (e < k) atomicAdd(a.dP + (int64_t)cur_u * k + e, dp[r]); }
-        if (lane == 0) a.dirtyP[cur_u] = 1u;
+                for (int r = 0; r < KR; ++r) YUE_BATOMIC(dp[r], rsdP, vo[r], ou[t]);
+                if (lane == 0) a.dirtyP[ru_[t]] = 1u;
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
+            run_ok = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
     if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);
 }
 
-// Round end: every row touched in [e_begin, e_end) gets its summed difference added once.
-// A row is claimed by whichever lane swaps its dirty flag back to 0 first.
-__device__ __forceinline__ void apply_row(float *X, float *dX, int64_t row, int k, int lane) {
-    for (int e = lane; e < k; e += 64) {
-        const int64_t o = row * k + e;
-        X[o] += dX[o];
-        dX[o] = 0.0f;
-    }
-}
+// Round end: every contended item row (count > 1) and every touched user row gets its summed
+// difference added once.  A row is claimed by whichever lane swaps its count / dirty flag back to
+// 0 first.  One wave takes 8 events = up to 24 claims (lanes 0-7: Q[i], 8-15: Q[j], 16-23: P[u]);
+// the winners are applied four at a time, one 16-lane group per row.
+constexpr int kApplyEvents = 8;
 
-__global__ void __launch_bounds__(256) k_apply_round(TrainArgs a, int64_t e_begin, int64_t e_end, int apply_p) {
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_apply_round(TrainArgs a, int64_t e_begin, int64_t e_end, uint32_t *cnt_cur, int apply_p) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t base = e_begin + wave * 32;
+    const int64_t base = e_begin + wave * kApplyEvents;
     if (base >= e_end) return;
-    const int64_t e = base + (lane & 31);
-    const bool valid = e < e_end;
+    const int kind = lane >> 3;                 // 0: i, 1: j, 2: u
+    const int64_t e = base + (lane & 7);
     int32_t row = -1;
-    if (valid) row = lane < 32 ? a.ev_i[e] : a.ev_j[e];
-    uint32_t won = 0;
-    if (row >= 0) won = atomicExch(a.dirtyQ + row, 0u);
-    unsigned long long mask = __ballot(won != 0u);
-    while (mask) {
-        const int b = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        apply_row(a.Q, a.dQ, __builtin_amdgcn_readlane(row, b), a.k, lane);
+    if (e < e_end && kind < (apply_p ? 3 : 2)) {
+        const int32_t jj = a.ev_j[e];
+        if (jj >= 0) row = kind == 0 ? a.ev_i[e] : kind == 1 ? jj : a.ev_u[e];   // a skipped triplet touched nothing
     }
-    if (apply_p) {
-        // consecutive events mostly share the user: only the first lane of a run tries the claim
-        int32_t ur = (valid && lane < 32) ? a.ev_u[e] : -1;
-        const int32_t prev = __shfl_up(ur, 1);
-        if (lane != 0 && prev == ur) ur = -1;
-        won = 0;
-        if (ur >= 0) won = atomicExch(a.dirtyP + ur, 0u);
-        mask = __ballot(won != 0u);
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            apply_row(a.P, a.dP, __builtin_amdgcn_readlane(ur, b), a.k, lane);
+    const int32_t prev = __shfl_up(row, 1);
+    bool won = false;
+    if (row >= 0) {
+        if (kind < 2) { if (cnt_cur[row] > 1u) won = atomicExch(cnt_cur + row, 0u) > 1u; }
+        else if ((lane & 7) == 0 || prev != row) won = atomicExch(a.dirtyP + row, 0u) != 0u;
+    }
+    unsigned long long mask = __ballot(won);
+    const int g = lane >> 4, gl = lane & 15;
+    const int k = a.k;
+    while (mask) {
+        unsigned long long mm = mask;
+        for (int t = 0; t < g; ++t) mm &= mm - 1;               // group g takes the g-th winner
+        const int src = mm ? __ffsll((long long)mm) - 1 : 0;
+        const int32_t r = __shfl(row, src);
+        if (mm) {
+            float *X = src >= 16 ? a.P : a.Q;
+            float *dX = src >= 16 ? a.dP : a.dQ;
+            const int64_t o = (int64_t)r * k;
+            if (VEC4) {
+                for (int c = gl * 4; c < k; c += 64) {
+                    float4 x = *reinterpret_cast<float4 *>(X + o + c);
+                    const float4 d = *reinterpret_cast<const float4 *>(dX + o + c);
+                    x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+                    *reinterpret_cast<float4 *>(X + o + c) = x;
+                    *reinterpret_cast<float4 *>(dX + o + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                for (int c = gl; c < k; c += 16) { X[o + c] += dX[o + c]; dX[o + c] = 0.0f; }
+            }
         }
+        mask &= mask - 1; mask &= mask - 1; mask &= mask - 1; mask &= mask - 1;
     }
 }
 
@@ -237,12 +393,11 @@ __global__ void __launch_bounds__(256) k_sumsq(const float *X, int64_t count, do
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ void __launch_bounds__(256) k_sum_slots(const double *slots, int nslots, double *out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int t = 0; t < nslots; ++t) s += slots[t];
-        *out = s;
-    }
+__global__ void __launch_bounds__(64) k_sum_slots(const double *slots, int nslots, double *out) {
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nslots; t += 64) s += slots[t];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) *out = s;
 }
 
 }  // namespace yue

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,7 +61,7 @@ struct yue_ctx {
     int k = 0;
     bool have_factors = false, have_inter = false;
     DevBuf<float> P, Q, dP, dQ;
-    DevBuf<uint32_t> dirtyP, dirtyQ;
+    DevBuf<uint32_t> dirtyP, cnt0, cnt1;   // cnt*: item-row touches of the even / odd round
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> xu, xi, xj;          // explicit triplets (replay / rounds)
@@ -85,12 +86,12 @@ struct yue_ctx {
 
 namespace {
 
-int kr_of(int k) { return k <= 32 ? 1 : k <= 64 ? 2 : k <= 128 ? 4 : 8; }
+int kr_of(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : 4; }   // registers per lane per row (64 lanes)
 
 yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
     yue::TrainArgs a{};
     a.P = c->P.p; a.Q = c->Q.p; a.dP = c->dP.p; a.dQ = c->dQ.p;
-    a.dirtyP = c->dirtyP.p; a.dirtyQ = c->dirtyQ.p;
+    a.dirtyP = c->dirtyP.p;
     a.ev_u = c->ev_u.p; a.ev_i = c->ev_i.p; a.ev_j = c->ev_j.p;
     a.indptr = c->indptr.p; a.indices = c->indices.p;
     a.nll_slots = c->scal.p;
@@ -102,22 +103,37 @@ yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
     return a;
 }
 
-template <bool SAMPLE, bool DIRECT>
-void launch_update(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int tpw) {
+void launch_level(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1) {
+    // enough waves to cover the chip before a wave takes more triplets of the level
+    const int tpw = (int)std::min<int64_t>(64, std::max<int64_t>(1, (e1 - e0) / 4096));
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     switch (kr_of(c->k)) {
-        case 1: hipLaunchKernelGGL((yue::k_bpr_update<1, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
-        case 2: hipLaunchKernelGGL((yue::k_bpr_update<2, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
-        case 4: hipLaunchKernelGGL((yue::k_bpr_update<4, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
-        default: hipLaunchKernelGGL((yue::k_bpr_update<8, SAMPLE, DIRECT>), grid, block, 0, c->stream, a, e0, e1, tpw); break;
+        case 1: hipLaunchKernelGGL(yue::k_bpr_level<1>, grid, block, 0, c->stream, a, e0, e1, tpw); break;
+        case 2: hipLaunchKernelGGL(yue::k_bpr_level<2>, grid, block, 0, c->stream, a, e0, e1, tpw); break;
+        default: hipLaunchKernelGGL(yue::k_bpr_level<4>, grid, block, 0, c->stream, a, e0, e1, tpw); break;
     }
 }
 
-// Bracket every timing_stride-th update launch with HIP events on the library's stream.
-template <bool SAMPLE, bool DIRECT>
-int timed_update(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int tpw) {
-    const bool timed = c->timing_stride > 0 && (c->launch_counter++ % c->timing_stride) == 0;
+int tpw_of(int k) {
+    int tpw = kr_of(k) == 4 ? 4 : 8;
+    if (const char *ev = std::getenv("YUE_TPW")) tpw = std::atoi(ev);      // tuning knob
+    return tpw;
+}
+
+// One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
+// Every timing_stride-th launch is bracketed with HIP events on the library's stream.
+int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
+                 uint32_t *cnt_cur, uint32_t *cnt_next, int sample_next) {
+    yue::RoundArgs ra{};
+    ra.e_begin = e0; ra.e_end = e1; ra.n_begin = n0; ra.n_end = n1;
+    ra.cnt_cur = cnt_cur; ra.cnt_next = cnt_next; ra.sample_next = sample_next;
+    ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
+    const int tpw = tpw_of(c->k);
+    const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
+    const int64_t blocks = ra.prep_blocks + (waves + 3) / 4;
+    if (blocks == 0) return YUE_OK;
+    const bool timed = e1 > e0 && c->timing_stride > 0 && (c->launch_counter++ % c->timing_stride) == 0;
     if (timed) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t s, t;
@@ -128,7 +144,17 @@ int timed_update(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
         }
         HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].first, c->stream));
     }
-    launch_update<SAMPLE, DIRECT>(c, a, e0, e1, tpw);
+    const dim3 grid((unsigned)blocks), block(256);
+    switch (kr_of(c->k) * 16 + tpw) {
+        case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra); break;
+        case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round<2, 8>), grid, block, 0, c->stream, a, ra); break;
+        case 4 * 16 + 4: hipLaunchKernelGGL((yue::k_round<4, 4>), grid, block, 0, c->stream, a, ra); break;
+        case 1 * 16 + 4: hipLaunchKernelGGL((yue::k_round<1, 4>), grid, block, 0, c->stream, a, ra); break;
+        case 2 * 16 + 4: hipLaunchKernelGGL((yue::k_round<2, 4>), grid, block, 0, c->stream, a, ra); break;
+        case 1 * 16 + 2: hipLaunchKernelGGL((yue::k_round<1, 2>), grid, block, 0, c->stream, a, ra); break;
+        case 2 * 16 + 2: hipLaunchKernelGGL((yue::k_round<2, 2>), grid, block, 0, c->stream, a, ra); break;
+        default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
+    }
     if (timed) {
         HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
         c->ev_triplets[c->ev_used] = e1 - e0;
@@ -137,15 +163,39 @@ int timed_update(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
     return YUE_OK;
 }
 
-void launch_apply(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int apply_p) {
-    const int64_t waves = (e1 - e0 + 31) / 32;
-    hipLaunchKernelGGL(yue::k_apply_round, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, a, e0, e1, apply_p);
+void launch_apply(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, uint32_t *cnt_cur, int apply_p) {
+    const int64_t waves = (e1 - e0 + yue::kApplyEvents - 1) / yue::kApplyEvents;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (c->k % 4 == 0) hipLaunchKernelGGL(yue::k_apply_round<true>, grid, block, 0, c->stream, a, e0, e1, cnt_cur, apply_p);
+    else hipLaunchKernelGGL(yue::k_apply_round<false>, grid, block, 0, c->stream, a, e0, e1, cnt_cur, apply_p);
 }
 
-int tpw_for(int64_t round_events) {
-    // enough waves to cover the chip (256 CUs x >= 8 waves) before a wave takes more events
-    int tpw = (int)std::min<int64_t>(64, std::max<int64_t>(1, round_events / 4096));
-    return tpw;
+// Runs the non-empty rounds bounds[r]..bounds[r+1] in order.  after_round(r) is called once the
+// launches of round r are queued (the communicator path hooks its all-reduce there).
+template <typename F>
+int run_rounds(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int64_t> &bounds, int sample, int apply_p, F after_round) {
+    const int64_t R = (int64_t)bounds.size() - 1;
+    std::vector<int64_t> ne;                                // indices of non-empty rounds
+    for (int64_t r = 0; r < R; ++r) if (bounds[(size_t)r + 1] > bounds[(size_t)r]) ne.push_back(r);
+    uint32_t *cnt[2] = {c->cnt0.p, c->cnt1.p};
+    int rc;
+    if (!ne.empty()) {      // prologue: negatives + touch counts of the first round
+        const int64_t r0 = ne[0];
+        if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], cnt[1], cnt[0], sample))) return rc;
+    }
+    size_t pos = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        if (pos < ne.size() && ne[pos] == r) {
+            const int64_t e0 = bounds[(size_t)r], e1 = bounds[(size_t)r + 1];
+            int64_t n0 = 0, n1 = 0;
+            if (pos + 1 < ne.size()) { n0 = bounds[(size_t)ne[pos + 1]]; n1 = bounds[(size_t)ne[pos + 1] + 1]; }
+            if ((rc = launch_round(c, a, e0, e1, n0, n1, cnt[pos & 1], cnt[(pos + 1) & 1], sample))) return rc;
+            launch_apply(c, a, e0, e1, cnt[pos & 1], apply_p);
+            ++pos;
+        }
+        if ((rc = after_round(r))) return rc;
+    }
+    return YUE_OK;
 }
 
 int zero_scalars(yue_ctx *c) {
@@ -214,7 +264,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
-    c->dirtyP.release(); c->dirtyQ.release();
+    c->dirtyP.release(); c->cnt0.release(); c->cnt1.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
@@ -235,18 +285,20 @@ int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64
     if (!c || !P || !Q) return fail(YUE_ERR_ARG, "yue_set_factors: null argument");
     if (m <= 0 || n <= 0 || k <= 0 || k > 256) return fail(YUE_ERR_ARG, "yue_set_factors: need m,n > 0 and 1 <= k <= 256");
     if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: ids must fit int32");
+    if (n * (int64_t)k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: the item matrix of one GPU must stay below 2 GiB (n*k*4 < 2^31): shard the items");
     HIPCHK(hipSetDevice(c->device));
     if (c->have_inter && (m != c->m || n != c->n)) c->have_inter = false;   // new shape: interactions must be uploaded again
     c->m = m; c->n = n; c->k = k;
     HIPCHK(c->P.resize(m * k)); HIPCHK(c->Q.resize(n * k));
     HIPCHK(c->dP.resize(m * k)); HIPCHK(c->dQ.resize(n * k));
-    HIPCHK(c->dirtyP.resize(m)); HIPCHK(c->dirtyQ.resize(n));
+    HIPCHK(c->dirtyP.resize(m)); HIPCHK(c->cnt0.resize(n)); HIPCHK(c->cnt1.resize(n));
     HIPCHK(hipMemcpyAsync(c->P.p, P, m * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->Q.p, Q, n * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->dP.p, 0, m * k * sizeof(float), c->stream));
     HIPCHK(hipMemsetAsync(c->dQ.p, 0, n * k * sizeof(float), c->stream));
     HIPCHK(hipMemsetAsync(c->dirtyP.p, 0, m * sizeof(uint32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->dirtyQ.p, 0, n * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->cnt0.p, 0, n * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->cnt1.p, 0, n * sizeof(uint32_t), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_factors = true;
     return YUE_OK;
@@ -276,6 +328,11 @@ int yue_set_interactions(yue_ctx *c, const int64_t *indptr, const int32_t *indic
         if (indptr[u + 1] - indptr[u] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: a user listened to every item (the reference's sampler would never return, BPR.py:47)");
     }
     const int64_t nnz = indptr[m], E = ev_ptr[m];
+    {   // the update kernel addresses P relative to a batch's first user with 31-bit byte offsets
+        int64_t prev = -1, max_gap = 0;
+        for (int64_t u = 0; u < m; ++u) if (ev_ptr[u + 1] > ev_ptr[u]) { if (prev >= 0) max_gap = std::max(max_gap, u - prev); prev = u; }
+        if (max_gap * c->k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_interactions: more than 2 GiB of user-factor rows between two consecutive users with events");
+    }
     std::vector<int32_t> evu((size_t)E);
     for (int64_t u = 0; u < m; ++u)
         for (int64_t e = ev_ptr[u]; e < ev_ptr[u + 1]; ++e) {
@@ -335,7 +392,7 @@ int yue_bpr_replay(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     if ((rc = zero_scalars(c))) return rc;
     for (int32_t l = 1; l <= nlev; ++l) {
         const int64_t e0 = lptr[(size_t)l], e1 = lptr[(size_t)l + 1];
-        if (e1 > e0) launch_update<false, true>(c, a, e0, e1, tpw_for(e1 - e0));
+        if (e1 > e0) launch_level(c, a, e0, e1);
     }
     HIPCHK(hipGetLastError());
     return read_scalars(c, nll_out, nullptr, nullptr);
@@ -354,12 +411,8 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     yue::TrainArgs a = make_args(c, lr, regU, regI);
     a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
     if ((rc = zero_scalars(c))) return rc;
-    for (int64_t r = 0; r < n_rounds; ++r) {
-        const int64_t e0 = round_ptr[r], e1 = round_ptr[r + 1];
-        if (e1 <= e0) continue;
-        if ((rc = timed_update<false, false>(c, a, e0, e1, tpw_for(e1 - e0)))) return rc;
-        launch_apply(c, a, e0, e1, 1);
-    }
+    std::vector<int64_t> bounds(round_ptr, round_ptr + n_rounds + 1);
+    if ((rc = run_rounds(c, a, bounds, 0, 1, [](int64_t) { return YUE_OK; }))) return rc;
     HIPCHK(hipGetLastError());
     return read_scalars(c, nll_out, nullptr, nullptr);
 }
@@ -402,38 +455,34 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     int rc = zero_scalars(c);
     if (rc) return rc;
     const int64_t E = c->E;
+    std::vector<int64_t> bounds;
     if (!c->comm) {
-        const int tpw = tpw_for(round_events);
-        for (int64_t e0 = 0; e0 < E; e0 += round_events) {
-            const int64_t e1 = std::min(E, e0 + round_events);
-            if ((rc = timed_update<true, false>(c, a, e0, e1, tpw))) return rc;
-            launch_apply(c, a, e0, e1, 1);
-        }
+        for (int64_t e0 = 0; e0 < E; e0 += round_events) bounds.push_back(e0);
+        bounds.push_back(E);
+        if ((rc = run_rounds(c, a, bounds, 1, 1, [](int64_t) { return YUE_OK; }))) return rc;
     } else {
         // Same user blocks on every rank: the block width comes from the job-wide event count.
         double etot = (double)E;
         if ((rc = yue_allreduce_f64(c, &etot, 1))) return rc;
+        if ((rc = zero_scalars(c))) return rc;            // the all-reduce used the scalar scratch
         const double per_user = etot / (double)c->nranks / (double)c->m;
         const int64_t ub = std::max<int64_t>(1, (int64_t)std::llround((double)round_events / std::max(per_user, 1e-9)));
         // all-reduce granularity: at least ~8 MB of user-factor differences per collective
         const int64_t group = std::max<int64_t>(1, (8ll << 20) / std::max<int64_t>(1, ub * c->k * 4));
-        int64_t in_group = 0, g_first = 0;
-        for (int64_t u0 = 0; u0 < c->m; u0 += ub) {
-            const int64_t u1 = std::min(c->m, u0 + ub);
-            const int64_t e0 = c->h_ev_ptr[(size_t)u0], e1 = c->h_ev_ptr[(size_t)u1];
-            if (in_group == 0) g_first = u0;
-            if (e1 > e0) {
-                if ((rc = timed_update<true, false>(c, a, e0, e1, tpw_for(e1 - e0)))) return rc;
-                launch_apply(c, a, e0, e1, 0);
-            }
-            if (++in_group == group || u1 == c->m) {
-                const int64_t first = g_first * c->k, count = (u1 - g_first) * c->k;
-                NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->stream));
-                hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->stream,
-                                   c->P.p, c->dP.p, c->dirtyP.p, first, count, c->k);
-                in_group = 0;
-            }
-        }
+        std::vector<int64_t> ublock;
+        for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
+        ublock.push_back(c->m); bounds.push_back(E);
+        const int64_t R = (int64_t)ublock.size() - 1;
+        auto after = [&](int64_t r) -> int {
+            if ((r + 1) % group != 0 && r + 1 != R) return YUE_OK;
+            const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
+            const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
+            NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->stream));
+            hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->stream,
+                               c->P.p, c->dP.p, c->dirtyP.p, first, count, c->k);
+            return YUE_OK;
+        };
+        if ((rc = run_rounds(c, a, bounds, 1, 0, after))) return rc;
     }
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
