@@ -32,7 +32,11 @@ WORKLOADS = {
     'c3': (1000000, 200000, 50, 128),
     'c2': (100000, 50000, 50, 64),
     'tiny': (20000, 5000, 20, 128),
+    # scoring (BASELINE config 5): all users x all items, top-20 selection, training items masked
+    'c5': (1000000, 200000, 50, 128),
+    'c5small': (65536, 200000, 50, 128),
 }
+MFMA_F32_PEAK = 157.3e12   # dense f32-input MFMA, MI355X (MI355X_MICROARCH.md)
 LR, REG_U, REG_I = 0.02, 0.01, 0.01
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 
@@ -72,6 +76,43 @@ def _cpu_name():
     return 'unknown cpu'
 
 
+def bench_scoring(args, cp):
+    """Secondary line: evalRanking's scoring + selection for every user (C5).  One step = one scan."""
+    m, n, d, k = WORKLOADS[args.workload]
+    N = 20
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    dev = Device(cp.local_rank, raise_errors=True)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    lo, hi = cp.rank * m // cp.world, (cp.rank + 1) * m // cp.world        # users shard over GPUs, no collective
+    users = np.arange(lo, hi, dtype=np.int32)
+    for _ in range(args.warmup):
+        dev.topn_scan(users, N)
+    cp.barrier()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        ids, sc = dev.topn_scan(users, N)
+        ms, events = dev.scan_stats()
+        kms += ms
+    cp.barrier()
+    dt = cp.reduce_max(time.perf_counter() - t0)
+    if cp.rank == 0:
+        flop = 2.0 * len(users) * n * k
+        ach = flop * args.steps / (kms * 1e-3)
+        print(json.dumps({
+            'metric': 'top-%d scoring users/sec (P.Q^T + overwrite-scan selection), k=%d' % (N, k), 'value': m * args.steps / dt,
+            'unit': 'users/s', 'n_gpus': cp.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: %d users x %d items, k=%d, N=%d, training items masked, host copies of ids/scores included in value'
+                                   % (args.workload.upper(), m, n, k, N), 'state_machine_events_per_user': events / max(1, len(users))},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_topn_scan<K2=%d>' % (k // 2), 'achieved': ach / 1e12, 'peak': MFMA_F32_PEAK / 1e12,
+                         'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK, 'kernel_ms_per_scan': kms / args.steps, 'traffic': None}}))
+    dev.close()
+    cp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -89,6 +130,8 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
         args.gpus = world
 
+    if args.workload.startswith('c5'):
+        return bench_scoring(args, cp)
     m, n, d, k = WORKLOADS[args.workload]
     t_setup = time.perf_counter()
     data = synth.make_arrays(m, n, d, seed=20260001 + 7919 * rank)     # this rank's item shard

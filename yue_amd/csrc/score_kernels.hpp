@@ -12,9 +12,11 @@
 //
 // k_topn_scan: a workgroup = 4 waves = 128 users; each wave keeps its 32 users' factor rows in
 // registers as MFMA A-operands and sweeps all items in tiles of 32 (B-operand tile shared by the
-// 4 waves through LDS, double buffered).  After the 32x32 tile's MFMA chain, the tile is parked
-// in LDS and lane r (< 32) walks user r's 32 scores in ascending item id through the reference's
-// state machine, whose N slots live in LDS.
+// 4 waves through LDS, double buffered, fetched one tile ahead).  After the 32x32 tile's MFMA
+// chain the scores are tested against the users' running thresholds in the accumulator registers;
+// the survivors (a few per tile) are parked in LDS with a per-user column mask, and lane r (< 32)
+// feeds user r's survivors in ascending item id through the reference's state machine, whose N
+// slots live in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,7 +58,8 @@ __host__ __device__ inline size_t scan_lds_bytes(int K2, int N) {
     const size_t tile = 2u * kScanTile * (2 * K2 + 1) * sizeof(float);
     const size_t park = (size_t)kScanWaves * 32 * kScLd * sizeof(float);
     const size_t state = (size_t)kScanWaves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
-    return tile + park + state;
+    const size_t sel = (size_t)kScanWaves * 32 * (sizeof(float) + sizeof(uint32_t));     // thresholds + candidate masks
+    return tile + park + state + sel;
 }
 
 template <int K2>
@@ -68,10 +71,14 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
     float *park_all = tile + 2 * kScanTile * LD;                            // [4][32][kScLd]
     float *st_a_all = park_all + kScanWaves * 32 * kScLd;                   // [4][32][NS]
     int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + kScanWaves * 32 * NS);
+    float *thr_all = reinterpret_cast<float *>(st_id_all + kScanWaves * 32 * NS);         // [4][32]
+    uint32_t *pm_all = reinterpret_cast<uint32_t *>(thr_all + kScanWaves * 32);           // [4][32]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     float *park = park_all + w * 32 * kScLd;
+    float *thr_w = thr_all + w * 32;
+    uint32_t *pm_w = pm_all + w * 32;
     float *st_a = st_a_all + (w * 32 + r) * NS;       // lane r's user (used by lanes < 32)
     int32_t *st_id = st_id_all + (w * 32 + r) * NS;
 
@@ -88,13 +95,24 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
     for (int idx = tid; idx < 2 * kScanTile * LD; idx += 256) tile[idx] = 0.0f;
     __syncthreads();
 
-    auto stage = [&](int buf, int64_t it0) {
+    // Item tiles travel global -> registers (issued one tile ahead, before the MFMA chain) -> LDS
+    // (written after it), so the global latency hides under the previous tile's arithmetic.
+    constexpr int PF = (kScanTile * 2 * K2 + 255) / 256;
+    const int tile_elems = kScanTile * k;
+    int lds_off[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { const int idx = tid + 256 * q; const int row = idx / k; lds_off[q] = row * LD + (idx - row * k); }
+    float pre[PF];
+    auto fetch = [&](int64_t it0) {
+        const int64_t limit = (a.n - it0) * k;                      // elements of Q left from this tile on
+        const float *src = a.Q + it0 * k;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { const int idx = tid + 256 * q; pre[q] = (idx < tile_elems && idx < limit) ? src[idx] : 0.0f; }
+    };
+    auto commit = [&](int buf) {
         float *dst = tile + buf * kScanTile * LD;
-        for (int idx = tid; idx < kScanTile * k; idx += 256) {
-            const int row = idx / k, col = idx - row * k;
-            const int64_t item = it0 + row;
-            dst[row * LD + col] = item < a.n ? a.Q[item * k + col] : 0.0f;
-        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) if (tid + 256 * q < tile_elems) dst[lds_off[q]] = pre[q];
     };
 
     // per-user scan state (lanes < 32)
@@ -108,17 +126,20 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
         mcur = a.mask_ptr[mrow]; mend = a.mask_ptr[mrow + 1];
         if (mcur < mend) mnext = a.mask_idx[mcur];
     }
+    if (h == 0) thr_w[r] = -INFINITY;
     float *g_sc = a.out_scores + (uvalid ? upos : 0) * N;     // also the unsorted-seed scratch
     int32_t *g_id = a.out_ids + (uvalid ? upos : 0) * N;
 
     const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
-    stage(0, 0);
+    fetch(0);
+    commit(0);
     __syncthreads();
 
     for (int64_t t = 0; t < ntiles; ++t) {
         const int cur = (int)(t & 1);
         const int64_t it0 = t * kScanTile;
         const float *bt = tile + cur * kScanTile * LD + r * LD + h;
+        if (t + 1 < ntiles) fetch(it0 + kScanTile);
 
         f32x16 acc;
 #pragma unroll
@@ -126,10 +147,19 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
 #pragma unroll
         for (int s = 0; s < K2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bt[2 * s], acc, 0, 0, 0);
 
-        // park the tile: acc[q] is user row (q&3)+8*(q>>2)+4*h, item column r
+        // Threshold test in the accumulator registers: acc[q] is user row (q&3)+8*(q>>2)+4*h, item
+        // column r.  A stale (lower) threshold only lets more candidates through; the state
+        // machine below re-checks exactly.  Per row the passing columns become a 32-bit mask.
+        const bool colok = it0 + r < a.n;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) park[((q & 3) + 8 * (q >> 2) + 4 * h) * kScLd + r] = acc[q];
-        if (t + 1 < ntiles) stage(cur ^ 1, it0 + kScanTile);
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const bool pass = colok && (thr_w[row] < acc[q]);
+            const unsigned long long b = __ballot(pass);
+            if (pass) park[row * kScLd + r] = acc[q];
+            if (r == 0) pm_w[row] = h ? (uint32_t)(b >> 32) : (uint32_t)b;
+        }
+        if (t + 1 < ntiles) commit(cur ^ 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 
@@ -141,12 +171,13 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
                 ++mcur;
                 mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
             }
-            const int ncol = (int)((a.n - it0) < kScanTile ? (a.n - it0) : kScanTile);
+            uint32_t cand = pm_w[r] & ~mb;
             const float *row = park + r * kScLd;
-            for (int c = 0; c < ncol; ++c) {
+            while (cand) {
+                const int c = __ffs(cand) - 1;
+                cand &= cand - 1;
                 const float s = row[c];
                 if (cnt == N && !(thr < s)) continue;
-                if ((mb >> c) & 1u) continue;
                 const int32_t item = (int32_t)(it0 + c);
                 ++events;
                 if (cnt < N) {
@@ -176,6 +207,7 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
                     thr = st_a[N - 1];
                 }
             }
+            thr_w[r] = thr;
         }
         __syncthreads();
     }
