@@ -66,6 +66,19 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=15.0):
                       '(restates recommender/cf/BPR.py:42-58), %.1f s on %s' % (S, dt, _cpu_name())}
 
 
+def measured_traffic(workload, round_events):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if that profile
+    was taken on another workload / round size."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+        if t['workload'] == workload and t['round_events'] == round_events:
+            return t['traffic_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def _cpu_name():
     try:
         for ln in open('/proc/cpuinfo'):
@@ -187,12 +200,12 @@ def main():
                                    % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),
                        'round_events': args.round_events, 'parallelism': 'items sharded x%d, users replicated' % world,
                        'setup_s': round(setup_s, 1), 'final_nll_per_triplet': nll / E},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + next-round sampler blocks)' % (1 if k <= 32 else 2 if k <= 64 else 4 if k <= 128 else 8),
+            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + next-round sampler blocks)' % (1 if k <= 64 else 2 if k <= 128 else 4),
                          'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                          'algorithmic_bytes_per_triplet': ab, 'launches_timed': k_launches,
                          'avg_launch_ms': (k_ms / k_launches) if k_launches else None,
                          'triplets_per_launch': (k_triplets / k_launches) if k_launches else None,
-                         'traffic': None},
+                         'traffic': measured_traffic(args.workload, args.round_events)},
         }
         if world == 1 and not args.no_cpu_baseline:
             j0 = dev.sample_negatives(seed, 0)
