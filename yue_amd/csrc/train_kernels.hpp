@@ -20,7 +20,6 @@ constexpr int kMaxAttempts = 64;
 
 struct TrainArgs {
     float *P, *Q, *dP, *dQ;
-    uint32_t *dirtyP;
     const int32_t *ev_u, *ev_i;
     int32_t *ev_j;
     const int64_t *indptr;
@@ -41,6 +40,9 @@ struct RoundArgs {
     int64_t n_begin, n_end;      // events of the NEXT round: negatives drawn and row touches counted here
     uint32_t *cnt_cur;           // touches per item row in [e_begin, e_end)   (filled by the previous launch)
     uint32_t *cnt_next;          // touches per item row in [n_begin, n_end)
+    uint32_t *cntp_cur;          // user-row flushes (runs of equal users inside a wave's batch) in this round
+    uint32_t *cntp_next;         // ... in the next round
+    int apply_p;                 // 1: user rows are finished in this launch; 0: dP is left for the all-reduce
     int sample_next;             // 1: draw ev_j for the next round (fused sampler); 0: ev_j is given
     int prep_blocks;             // blocks [0, prep_blocks) run the sample+count role
 };
@@ -179,8 +181,10 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 // pass (lane t holds triplet t), then writes:
 //   * an item row touched exactly once in the round (cnt == 1): the new row, in place, plain
 //     stores -- nobody else reads or writes it this round;
-//   * a contended row: (new - old) added into dQ with float atomics; k_apply_round adds dQ once.
-// P[u] differences are summed in registers over a run of equal users and flushed into dP.
+//   * a contended row: (new - old) added into dQ with float atomics; the last toucher of the row
+//     (touch count reaching zero) adds dQ to the row once and leaves dQ zeroed.
+// P[u] differences are summed in registers over a run of equal users and flushed into dP; user
+// rows are finished by the same last-arriver rule (or, on a communicator, by the all-reduce).
 // ------------------------------------------------------------------------------------------
 // Raw buffer access: one 128-bit descriptor per matrix in SGPRs, the row's byte offset in an SGPR
 // (soffset), the lane's element offset in one VGPR (voffset) -- no per-access address arithmetic in
@@ -203,6 +207,10 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
             if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
             else j = a.ev_j[e];
             if (j >= 0) { atomicAdd(ra.cnt_next + i, 1u); atomicAdd(ra.cnt_next + j, 1u); }
+            if (ra.apply_p) {      // one flush per run of equal users inside a TPW-aligned batch
+                const int32_t u = a.ev_u[e];
+                if ((e - ra.n_begin) % TPW == 0 || a.ev_u[e - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
+            }
         }
         return;
     }
@@ -276,6 +284,8 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
 #pragma unroll
     for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
     bool run_ok = false;                                 // some triplet of the current user run wrote
+    int nruns = 0;                                       // runs of equal users in this batch (wave-uniform)
+    unsigned run_u = 0;                                  // lane q holds the user of run q
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float c = rdlane(cs, t);
@@ -296,85 +306,68 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
             }
         }
         // end of a run of equal users (or of the batch): flush the summed P[u] differences
-        const bool last = (t == TPW - 1) || ru_[t + 1 < TPW ? t + 1 : t] != ru_[t];
+        const bool exists = base + t < ra.e_end;
+        const bool last = exists && ((t == TPW - 1) || base + t + 1 >= ra.e_end || ru_[t + 1 < TPW ? t + 1 : t] != ru_[t]);
         if (last) {
             if (run_ok) {
 #pragma unroll
                 for (int r = 0; r < KR; ++r) YUE_BATOMIC(dp[r], rsdP, vo[r], ou[t]);
-                if (lane == 0) a.dirtyP[ru_[t]] = 1u;
             }
+            run_u = lane == nruns ? ru_[t] : run_u;
+            ++nruns;
 #pragma unroll
             for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
             run_ok = false;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+
+    // Retire this batch's touches of contended rows.  Every toucher decrements the row's count once
+    // its own adds are acknowledged; whoever takes the count to zero knows every add of the round
+    // has been performed and every toucher has read the row: it swaps the sum out of dQ (returning
+    // atomic: coherent at the memory side, leaves dQ zeroed) and rewrites the row.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool last_i = false, last_j = false, last_p = false;
+    if (lane < TPW && j >= 0) {
+        if (ci != 1u) last_i = atomicSub(ra.cnt_cur + i, 1u) == 1u;
+        if (cj != 1u) last_j = atomicSub(ra.cnt_cur + j, 1u) == 1u;
+    }
+    if (ra.apply_p && lane < nruns) last_p = atomicSub(ra.cntp_cur + run_u, 1u) == 1u;
+    unsigned long long mi = __ballot(last_i), mj = __ballot(last_j), mp = __ballot(last_p);
+    while (mi | mj) {
+        const bool from_i = mi != 0;
+        const int b = __ffsll((long long)(from_i ? mi : mj)) - 1;
+        if (from_i) mi &= mi - 1; else mj &= mj - 1;
+        const unsigned row = (unsigned)__builtin_amdgcn_readlane(from_i ? i : j, b);
+        const uint64_t o = (uint64_t)row * k;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const unsigned e = 64u * r + lane;
+            if (e < k) { const float d = atomicExch(a.dQ + o + e, 0.0f); a.Q[o + e] += d; }
+        }
+    }
+    while (mp) {
+        const int b = __ffsll((long long)mp) - 1;
+        mp &= mp - 1;
+        const uint64_t o = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)run_u, b) * k;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const unsigned e = 64u * r + lane;
+            if (e < k) { const float d = atomicExch(a.dP + o + e, 0.0f); a.P[o + e] += d; }
+        }
+    }
 #pragma unroll
     for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
     if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);
 }
 
-// Round end: every contended item row (count > 1) and every touched user row gets its summed
-// difference added once.  A row is claimed by whichever lane swaps its count / dirty flag back to
-// 0 first.  One wave takes 8 events = up to 24 claims (lanes 0-7: Q[i], 8-15: Q[j], 16-23: P[u]);
-// the winners are applied four at a time, one 16-lane group per row.
-constexpr int kApplyEvents = 8;
-
-template <bool VEC4>
-__global__ void __launch_bounds__(256) k_apply_round(TrainArgs a, int64_t e_begin, int64_t e_end, uint32_t *cnt_cur, int apply_p) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t base = e_begin + wave * kApplyEvents;
-    if (base >= e_end) return;
-    const int kind = lane >> 3;                 // 0: i, 1: j, 2: u
-    const int64_t e = base + (lane & 7);
-    int32_t row = -1;
-    if (e < e_end && kind < (apply_p ? 3 : 2)) {
-        const int32_t jj = a.ev_j[e];
-        if (jj >= 0) row = kind == 0 ? a.ev_i[e] : kind == 1 ? jj : a.ev_u[e];   // a skipped triplet touched nothing
-    }
-    const int32_t prev = __shfl_up(row, 1);
-    bool won = false;
-    if (row >= 0) {
-        if (kind < 2) { if (cnt_cur[row] > 1u) won = atomicExch(cnt_cur + row, 0u) > 1u; }
-        else if ((lane & 7) == 0 || prev != row) won = atomicExch(a.dirtyP + row, 0u) != 0u;
-    }
-    unsigned long long mask = __ballot(won);
-    const int g = lane >> 4, gl = lane & 15;
-    const int k = a.k;
-    while (mask) {
-        unsigned long long mm = mask;
-        for (int t = 0; t < g; ++t) mm &= mm - 1;               // group g takes the g-th winner
-        const int src = mm ? __ffsll((long long)mm) - 1 : 0;
-        const int32_t r = __shfl(row, src);
-        if (mm) {
-            float *X = src >= 16 ? a.P : a.Q;
-            float *dX = src >= 16 ? a.dP : a.dQ;
-            const int64_t o = (int64_t)r * k;
-            if (VEC4) {
-                for (int c = gl * 4; c < k; c += 64) {
-                    float4 x = *reinterpret_cast<float4 *>(X + o + c);
-                    const float4 d = *reinterpret_cast<const float4 *>(dX + o + c);
-                    x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
-                    *reinterpret_cast<float4 *>(X + o + c) = x;
-                    *reinterpret_cast<float4 *>(dX + o + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else {
-                for (int c = gl; c < k; c += 16) { X[o + c] += dX[o + c]; dX[o + c] = 0.0f; }
-            }
-        }
-        mask &= mask - 1; mask &= mask - 1; mask &= mask - 1; mask &= mask - 1;
-    }
-}
-
 // Multi-GPU: after the all-reduce of dP[first .. first+count) the same range is applied everywhere.
-__global__ void __launch_bounds__(256) k_apply_range(float *X, float *dX, uint32_t *dirty, int64_t first_elem, int64_t count, int k) {
+__global__ void __launch_bounds__(256) k_apply_range(float *X, float *dX, int64_t first_elem, int64_t count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
         const int64_t o = first_elem + t;
         X[o] += dX[o];
         dX[o] = 0.0f;
-        if (t % k == 0) dirty[o / k] = 0u;
     }
 }
 

@@ -61,7 +61,7 @@ struct yue_ctx {
     int k = 0;
     bool have_factors = false, have_inter = false;
     DevBuf<float> P, Q, dP, dQ;
-    DevBuf<uint32_t> dirtyP, cnt0, cnt1;   // cnt*: item-row touches of the even / odd round
+    DevBuf<uint32_t> cnt0, cnt1, cntp0, cntp1;   // item-row touches / user-row flushes of the even / odd round
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> xu, xi, xj;          // explicit triplets (replay / rounds)
@@ -91,7 +91,6 @@ int kr_of(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : 4; }   // registers per l
 yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
     yue::TrainArgs a{};
     a.P = c->P.p; a.Q = c->Q.p; a.dP = c->dP.p; a.dQ = c->dQ.p;
-    a.dirtyP = c->dirtyP.p;
     a.ev_u = c->ev_u.p; a.ev_i = c->ev_i.p; a.ev_j = c->ev_j.p;
     a.indptr = c->indptr.p; a.indices = c->indices.p;
     a.nll_slots = c->scal.p;
@@ -124,10 +123,12 @@ int tpw_of(int k) {
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
 // Every timing_stride-th launch is bracketed with HIP events on the library's stream.
 int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
-                 uint32_t *cnt_cur, uint32_t *cnt_next, int sample_next) {
+                 int parity, int sample_next, int apply_p) {
+    uint32_t *cnt[2] = {c->cnt0.p, c->cnt1.p}, *cntp[2] = {c->cntp0.p, c->cntp1.p};
     yue::RoundArgs ra{};
     ra.e_begin = e0; ra.e_end = e1; ra.n_begin = n0; ra.n_end = n1;
-    ra.cnt_cur = cnt_cur; ra.cnt_next = cnt_next; ra.sample_next = sample_next;
+    ra.cnt_cur = cnt[parity]; ra.cnt_next = cnt[parity ^ 1]; ra.cntp_cur = cntp[parity]; ra.cntp_next = cntp[parity ^ 1];
+    ra.sample_next = sample_next; ra.apply_p = apply_p;
     ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
     const int tpw = tpw_of(c->k);
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
@@ -163,13 +164,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
     return YUE_OK;
 }
 
-void launch_apply(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, uint32_t *cnt_cur, int apply_p) {
-    const int64_t waves = (e1 - e0 + yue::kApplyEvents - 1) / yue::kApplyEvents;
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (c->k % 4 == 0) hipLaunchKernelGGL(yue::k_apply_round<true>, grid, block, 0, c->stream, a, e0, e1, cnt_cur, apply_p);
-    else hipLaunchKernelGGL(yue::k_apply_round<false>, grid, block, 0, c->stream, a, e0, e1, cnt_cur, apply_p);
-}
-
 // Runs the non-empty rounds bounds[r]..bounds[r+1] in order.  after_round(r) is called once the
 // launches of round r are queued (the communicator path hooks its all-reduce there).
 template <typename F>
@@ -177,11 +171,10 @@ int run_rounds(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int64_t> &
     const int64_t R = (int64_t)bounds.size() - 1;
     std::vector<int64_t> ne;                                // indices of non-empty rounds
     for (int64_t r = 0; r < R; ++r) if (bounds[(size_t)r + 1] > bounds[(size_t)r]) ne.push_back(r);
-    uint32_t *cnt[2] = {c->cnt0.p, c->cnt1.p};
     int rc;
     if (!ne.empty()) {      // prologue: negatives + touch counts of the first round
         const int64_t r0 = ne[0];
-        if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], cnt[1], cnt[0], sample))) return rc;
+        if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], 1, sample, apply_p))) return rc;
     }
     size_t pos = 0;
     for (int64_t r = 0; r < R; ++r) {
@@ -189,8 +182,7 @@ int run_rounds(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int64_t> &
             const int64_t e0 = bounds[(size_t)r], e1 = bounds[(size_t)r + 1];
             int64_t n0 = 0, n1 = 0;
             if (pos + 1 < ne.size()) { n0 = bounds[(size_t)ne[pos + 1]]; n1 = bounds[(size_t)ne[pos + 1] + 1]; }
-            if ((rc = launch_round(c, a, e0, e1, n0, n1, cnt[pos & 1], cnt[(pos + 1) & 1], sample))) return rc;
-            launch_apply(c, a, e0, e1, cnt[pos & 1], apply_p);
+            if ((rc = launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), sample, apply_p))) return rc;
             ++pos;
         }
         if ((rc = after_round(r))) return rc;
@@ -264,7 +256,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
-    c->dirtyP.release(); c->cnt0.release(); c->cnt1.release();
+    c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
@@ -291,12 +283,13 @@ int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64
     c->m = m; c->n = n; c->k = k;
     HIPCHK(c->P.resize(m * k)); HIPCHK(c->Q.resize(n * k));
     HIPCHK(c->dP.resize(m * k)); HIPCHK(c->dQ.resize(n * k));
-    HIPCHK(c->dirtyP.resize(m)); HIPCHK(c->cnt0.resize(n)); HIPCHK(c->cnt1.resize(n));
+    HIPCHK(c->cnt0.resize(n)); HIPCHK(c->cnt1.resize(n)); HIPCHK(c->cntp0.resize(m)); HIPCHK(c->cntp1.resize(m));
     HIPCHK(hipMemcpyAsync(c->P.p, P, m * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->Q.p, Q, n * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->dP.p, 0, m * k * sizeof(float), c->stream));
     HIPCHK(hipMemsetAsync(c->dQ.p, 0, n * k * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->dirtyP.p, 0, m * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->cntp0.p, 0, m * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->cntp1.p, 0, m * sizeof(uint32_t), c->stream));
     HIPCHK(hipMemsetAsync(c->cnt0.p, 0, n * sizeof(uint32_t), c->stream));
     HIPCHK(hipMemsetAsync(c->cnt1.p, 0, n * sizeof(uint32_t), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -479,7 +472,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
             const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
             NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->stream));
             hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->stream,
-                               c->P.p, c->dP.p, c->dirtyP.p, first, count, c->k);
+                               c->P.p, c->dP.p, first, count);
             return YUE_OK;
         };
         if ((rc = run_rounds(c, a, bounds, 1, 0, after))) return rc;
