@@ -98,7 +98,9 @@ int yue_scores(yue_ctx *ctx, int32_t user, float *out_n);
 /*
  * evalRanking's selection for nu users.  Masked items per user come from mask_indptr[nu+1] /
  * mask_indices (rows sorted ascending, indexed by position in users[]); pass NULL for both to
- * mask the uploaded training items (evalRanking).  out_ids[nu*N], out_scores[nu*N], 1 <= N <= 100 (the reference caps N at 100, :84-86); k <= 128.
+ * mask the uploaded training items (evalRanking).  out_ids[nu*N], out_scores[nu*N], 1 <= N <= 100 (the
+ * reference caps N at 100, :84-86); k <= 128.  Scores are the exact fp32 fma chain of yue_scores; for
+ * k in {16,32,64,128} a bf16 MFMA tile pre-filters the pairs that can matter (same results).
  * Returns YUE_ERR_FEW_ITEMS if some user has fewer than N candidates (their rows are -1 / -inf).
  */
 int yue_topn_scan(yue_ctx *ctx, const int32_t *users, int64_t nu, int N,
@@ -109,8 +111,14 @@ int yue_topn_scan(yue_ctx *ctx, const int32_t *users, int64_t nu, int N,
  * stride = 0 disables; otherwise every stride-th launch is bracketed. */
 int yue_set_kernel_timing(yue_ctx *ctx, int stride);
 int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_timed, int64_t *triplets_timed);
-/* Time of the last yue_topn_scan's scoring kernel (HIP events), and its candidate-event count. */
-int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events);
+/* Last yue_topn_scan: time of its scoring kernel (HIP events), state-machine events, exact re-scores
+ * done behind the bf16 pre-filter, and whether the bf16 pre-filter kernel ran (k in 16/32/64/128). */
+int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t *rescored, int *used_bf16);
+
+/* Tuning / diagnostic knobs (results do not depend on them):
+ *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
+ *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8 */
+int yue_set_option(yue_ctx *ctx, const char *name, int64_t value);
 
 /* Multi-GPU (one process per GPU, RCCL over xGMI).  Rank 0 creates the id, the caller ships
  * the 128 bytes to the other ranks (any side channel), every rank calls yue_comm_init. */

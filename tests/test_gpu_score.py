@@ -68,6 +68,8 @@ def test_lists_match_reference_golden(dev, orc, tag, N):
     (64, 2000, 128, 100, 10),     # largest N
     (33, 500, 16, 1, 5),
     (10, 97, 7, 3, 20),           # odd k (zero padded), tiny
+    (70, 1500, 32, 10, 40),
+    (40, 900, 48, 10, 40),        # k not in the bf16 set -> f32 kernel
 ])
 def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
     P, Q, indptr, indices = _rand_problem(m, n, k, per_user, seed=m + n + k + N)
@@ -79,8 +81,15 @@ def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
     assert rc == 0
     assert np.array_equal(ids, oid)
     assert np.array_equal(sc, osc)
-    ms, events = dev.scan_stats()
+    ms, events, rescored, used_bf16 = dev.scan_stats()
     assert ms > 0 and events >= len(users) * N
+    assert used_bf16 == (k in (16, 32, 64, 128)) and (not used_bf16 or rescored >= events)
+    # the exact f32-MFMA kernel and the bf16 pre-filter path give the same lists and scores
+    dev.set_option('scan_f32', 1)
+    ids2, sc2 = dev.topn_scan(users, N, mp, mi)
+    dev.set_option('scan_f32', 0)
+    assert not dev.scan_stats()[3]
+    assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
 
 
 def test_scan_with_ties_and_duplicates(dev, orc):

@@ -21,7 +21,7 @@ UNIQUE_ID_BYTES = 128
 SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy', 'yue_sync',
            'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
            'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
-           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats',
+           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64']
 
 
@@ -194,9 +194,13 @@ class Device(object):
         return ids, sc
 
     def scan_stats(self):
-        ms, ev = C.c_double(), C.c_int64()
-        self._chk(self._lib.yue_get_scan_stats(self._ctx, C.byref(ms), C.byref(ev)))
-        return ms.value, ev.value
+        """(kernel ms, state-machine events, exact re-scores, used_bf16) of the last topn_scan."""
+        ms, ev, rs, bf = C.c_double(), C.c_int64(), C.c_int64(), C.c_int()
+        self._chk(self._lib.yue_get_scan_stats(self._ctx, C.byref(ms), C.byref(ev), C.byref(rs), C.byref(bf)))
+        return ms.value, ev.value, rs.value, bool(bf.value)
+
+    def set_option(self, name, value):
+        self._chk(self._lib.yue_set_option(self._ctx, name.encode(), C.c_int64(value)))
 
     # -- measurement ----------------------------------------------------------------------
     def set_kernel_timing(self, stride):

@@ -35,8 +35,69 @@ struct ScanArgs {
     int mask_by_user;      // 1: mask row = user id (training CSR); 0: mask row = position in users[]
     int32_t *out_ids;
     float *out_scores;
-    int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events
+    int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events, [2] exact re-scores (bf16 path)
+    const float *item_norms;   // ||Q[i]||_2 per item (bf16 pre-filter margin); unused by the f32 kernel
 };
+
+// Per-user selection state: N slots in LDS + the running threshold (the reference's state machine,
+// base/IterativeRecommender.py:107-145).  Shared by the exact-f32 and the bf16-pre-filter kernels.
+struct ScanState {
+    float *st_a;           // LDS: scores, sorted descending
+    int32_t *st_id;        // LDS: item ids
+    float *g_sc;           // global scratch for the unsorted seeds = this user's output row
+    int32_t *g_id;
+    int cnt;
+    float thr;
+    int events;
+};
+
+__device__ __forceinline__ void scan_push(ScanState &S, int N, float s, int32_t item) {
+    ++S.events;
+    if (S.cnt < N) {
+        // seed phase (:107-112): keep id order in global scratch
+        S.g_sc[S.cnt] = s; S.g_id[S.cnt] = item;
+        // stable descending insertion (:114): later ids go after equal scores
+        int p = S.cnt;
+        while (p > 0 && S.st_a[p - 1] < s) { S.st_a[p] = S.st_a[p - 1]; S.st_id[p] = S.st_id[p - 1]; --p; }
+        S.st_a[p] = s; S.st_id[p] = item;
+        ++S.cnt;
+        if (S.cnt == N) {
+            // the scan (:121-144) starts over from the first candidate
+            for (int q = 0; q < N; ++q) {
+                const float sq = S.g_sc[q];
+                if (S.st_a[N - 1] < sq) {
+                    int p2 = 0;
+                    while (S.st_a[p2] >= sq) ++p2;
+                    S.st_a[p2] = sq; S.st_id[p2] = S.g_id[q];
+                }
+            }
+            S.thr = S.st_a[N - 1];
+        }
+    } else {
+        int p = 0;
+        while (S.st_a[p] >= s) ++p;            // first slot strictly below s
+        S.st_a[p] = s; S.st_id[p] = item;      // overwrite, no shift (:142-144)
+        S.thr = S.st_a[N - 1];
+    }
+}
+
+__device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *flags) {
+    if (S.cnt < N) {
+        atomicOr(flags, 1);
+        for (int q = 0; q < N; ++q) { S.g_sc[q] = -INFINITY; S.g_id[q] = -1; }
+    } else {
+        for (int q = 0; q < N; ++q) { S.g_sc[q] = S.st_a[q]; S.g_id[q] = S.st_id[q]; }
+    }
+    atomicAdd(flags + 1, S.events);
+}
+
+__global__ void __launch_bounds__(256) k_row_norms(const float *X, int64_t rows, int k, float *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.0f;
+    for (int e = 0; e < k; ++e) s = __builtin_fmaf(X[r * k + e], X[r * k + e], s);
+    out[r] = __builtin_sqrtf(s);
+}
 
 __global__ void __launch_bounds__(256) k_scores_one(const float *pu, const float *Q, int64_t n, int k, float *out) {
     const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,9 +177,10 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
     };
 
     // per-user scan state (lanes < 32)
-    int cnt = 0;
-    float thr = -INFINITY;
-    int events = 0;
+    ScanState S;
+    S.st_a = st_a; S.st_id = st_id; S.cnt = 0; S.thr = -INFINITY; S.events = 0;
+    S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;      // also the unsorted-seed scratch
+    S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
     int64_t mcur = 0, mend = 0;
     int32_t mnext = 0x7fffffff;
     if (h == 0 && uvalid) {
@@ -127,8 +189,6 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
         if (mcur < mend) mnext = a.mask_idx[mcur];
     }
     if (h == 0) thr_w[r] = -INFINITY;
-    float *g_sc = a.out_scores + (uvalid ? upos : 0) * N;     // also the unsorted-seed scratch
-    int32_t *g_id = a.out_ids + (uvalid ? upos : 0) * N;
 
     const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
     fetch(0);
@@ -177,71 +237,219 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
                 const int c = __ffs(cand) - 1;
                 cand &= cand - 1;
                 const float s = row[c];
-                if (cnt == N && !(thr < s)) continue;
-                const int32_t item = (int32_t)(it0 + c);
-                ++events;
-                if (cnt < N) {
-                    // seed phase (IterativeRecommender.py:107-112): keep id order in global scratch
-                    g_sc[cnt] = s; g_id[cnt] = item;
-                    // stable descending insertion (:114): later ids go after equal scores
-                    int p = cnt;
-                    while (p > 0 && st_a[p - 1] < s) { st_a[p] = st_a[p - 1]; st_id[p] = st_id[p - 1]; --p; }
-                    st_a[p] = s; st_id[p] = item;
-                    ++cnt;
-                    if (cnt == N) {
-                        // the scan (:121-144) starts over from the first candidate
-                        for (int q = 0; q < N; ++q) {
-                            const float sq = g_sc[q];
-                            if (st_a[N - 1] < sq) {
-                                int p2 = 0;
-                                while (st_a[p2] >= sq) ++p2;
-                                st_a[p2] = sq; st_id[p2] = g_id[q];
-                            }
-                        }
-                        thr = st_a[N - 1];
-                    }
-                } else {
-                    int p = 0;
-                    while (st_a[p] >= s) ++p;          // first slot strictly below s
-                    st_a[p] = s; st_id[p] = item;      // overwrite, no shift (:142-144)
-                    thr = st_a[N - 1];
-                }
+                if (S.cnt == N && !(S.thr < s)) continue;
+                scan_push(S, N, s, (int32_t)(it0 + c));
             }
-            thr_w[r] = thr;
+            thr_w[r] = S.thr;
         }
         __syncthreads();
     }
 
-    if (h == 0 && uvalid) {
-        if (cnt < N) {
-            atomicOr(a.flags, 1);
-            for (int q = 0; q < N; ++q) { g_sc[q] = -INFINITY; g_id[q] = -1; }
-        } else {
-            for (int q = 0; q < N; ++q) { g_sc[q] = st_a[q]; g_id[q] = st_id[q]; }
-        }
-        atomicAdd(a.flags + 1, events);
-    }
+    if (h == 0 && uvalid) scan_finish(S, N, a.flags);
 }
 
-inline int launch_scan(const ScanArgs &a, hipStream_t stream) {
+// ------------------------------------------------------------------------------------------
+// bf16 pre-filter in front of the exact path (k = 16*K16 <= 128).
+// The 32x32 tile of scores comes from v_mfma_f32_32x32x16_bf16 on bf16-rounded factors (1/16 of the
+// f32-MFMA time).  |bf16 score - exact score| <= 2^-8 * sum|p_e q_e| <= 2^-8 ||P_u|| ||Q_i||, so a
+// pair can only matter to the state machine if  bf16 score + 2^-7 ||P_u|| ||Q_i|| > threshold_u
+// (margin doubled for slack).  Those few survivors are re-scored exactly -- the same k-ascending
+// fp32 fma chain as k_topn_scan / the oracle, P row in registers, Q row from the fp32 LDS tile --
+// and only the exact score enters the state machine: results are identical to the f32 kernel.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t scan_bf16_lds_bytes(int k, int N) {
+    const size_t tile = 2u * kScanTile * (k + 4) * sizeof(float);
+    const size_t state = (size_t)kScanWaves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
+    const size_t sel = (size_t)kScanWaves * 32 * (2 * sizeof(float) + sizeof(uint32_t));   // thr, mu, masks
+    return tile + state + sel;
+}
+
+template <int K16>
+__global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int K = 16 * K16, LD = K + 4;
+    const int N = a.N, NS = scan_ns(N);
+    float *tile = reinterpret_cast<float *>(lds_raw);                       // [2][32][LD] fp32
+    float *st_a_all = tile + 2 * kScanTile * LD;
+    int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + kScanWaves * 32 * NS);
+    float *thr_all = reinterpret_cast<float *>(st_id_all + kScanWaves * 32 * NS);
+    float *mu_all = thr_all + kScanWaves * 32;
+    uint32_t *pm_all = reinterpret_cast<uint32_t *>(mu_all + kScanWaves * 32);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    float *thr_w = thr_all + w * 32, *mu_w = mu_all + w * 32;
+    uint32_t *pm_w = pm_all + w * 32;
+
+    const int64_t upos = (int64_t)blockIdx.x * (kScanWaves * 32) + w * 32 + r;
+    const bool uvalid = upos < a.nu;
+    const int32_t uid = a.users[uvalid ? upos : 0];
+    const float *prow = a.P + (int64_t)uid * K;
+
+    // exact fp32 row of user r (for the re-score chain) and its bf16 A fragments:
+    // lane (r,h) supplies A[row r][16*s + 8*h + j], j = 0..7, at step s
+    float pf[K];
+#pragma unroll
+    for (int e = 0; e < K; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(prow + e); pf[e] = v[0]; pf[e + 1] = v[1]; pf[e + 2] = v[2]; pf[e + 3] = v[3]; }
+    bf16x8 af[K16];
+#pragma unroll
+    for (int s = 0; s < K16; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) af[s][jj] = (__bf16)prow[16 * s + 8 * h + jj];
+    if (h == 0) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int e = 0; e < K; ++e) ss = __builtin_fmaf(pf[e], pf[e], ss);
+        mu_w[r] = __builtin_sqrtf(ss) * (1.01f / 128.0f);      // 2^-7 ||P_u||, 1 % slack for the norm roundings
+        thr_w[r] = -INFINITY;
+    }
+
+    // item tiles: global -> registers (one tile ahead) -> LDS, float4 granularity
+    constexpr int PF4 = (kScanTile * K / 4 + 255) / 256;
+    int lds_off[PF4];
+#pragma unroll
+    for (int q = 0; q < PF4; ++q) { const int el = (tid + 256 * q) * 4; const int row = el / K; lds_off[q] = row * LD + (el - row * K); }
+    f32x4 pre[PF4];
+    float nu_next = 0.0f;
+    auto fetch = [&](int64_t it0) {
+        const int64_t limit = (a.n - it0) * K;
+        const float *src = a.Q + it0 * K;
+#pragma unroll
+        for (int q = 0; q < PF4; ++q) {
+            const int el = (tid + 256 * q) * 4;
+            pre[q] = (el < kScanTile * K && el < limit) ? *reinterpret_cast<const f32x4 *>(src + el) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        nu_next = it0 + r < a.n ? a.item_norms[it0 + r] : 0.0f;
+    };
+    auto commit = [&](int buf) {
+        float *dst = tile + buf * kScanTile * LD;
+#pragma unroll
+        for (int q = 0; q < PF4; ++q) if ((tid + 256 * q) * 4 < kScanTile * K) *reinterpret_cast<f32x4 *>(dst + lds_off[q]) = pre[q];
+    };
+
+    ScanState S;
+    S.st_a = st_a_all + (w * 32 + r) * NS; S.st_id = st_id_all + (w * 32 + r) * NS;
+    S.cnt = 0; S.thr = -INFINITY; S.events = 0;
+    S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;
+    S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
+    int rescored = 0;
+    int64_t mcur = 0, mend = 0;
+    int32_t mnext = 0x7fffffff;
+    if (h == 0 && uvalid) {
+        const int64_t mrow = a.mask_by_user ? (int64_t)uid : upos;
+        mcur = a.mask_ptr[mrow]; mend = a.mask_ptr[mrow + 1];
+        if (mcur < mend) mnext = a.mask_idx[mcur];
+    }
+
+    const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
+    fetch(0);
+    commit(0);
+    float nu = nu_next;
+    __syncthreads();
+
+    for (int64_t t = 0; t < ntiles; ++t) {
+        const int cur = (int)(t & 1);
+        const int64_t it0 = t * kScanTile;
+        const float *tb = tile + cur * kScanTile * LD;
+        if (t + 1 < ntiles) fetch(it0 + kScanTile);
+
+        // bf16 scores: lane (r,h) supplies B[16*s + 8*h + j][col r] from item r's fp32 row
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        const float *brow = tb + r * LD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < K16; ++s) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(brow + 16 * s), b1 = *reinterpret_cast<const f32x4 *>(brow + 16 * s + 4);
+            bf16x8 bf;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { bf[jj] = (__bf16)b0[jj]; bf[jj + 4] = (__bf16)b1[jj]; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf, acc, 0, 0, 0);
+        }
+
+        // pre-filter: acc[q] is user row (q&3)+8*(q>>2)+4*h, item column r
+        const bool colok = it0 + r < a.n;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const bool pass = colok && (thr_w[row] < __builtin_fmaf(mu_w[row], nu, acc[q]));
+            const unsigned long long b = __ballot(pass);
+            if (r == 0) pm_w[row] = h ? (uint32_t)(b >> 32) : (uint32_t)b;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        if (h == 0 && uvalid) {
+            uint32_t mb = 0u;
+            while (mnext < it0 + kScanTile) {
+                mb |= 1u << (uint32_t)(mnext - it0);
+                ++mcur;
+                mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
+            }
+            uint32_t cand = pm_w[r] & ~mb;
+            while (cand) {
+                const int c = __ffs(cand) - 1;
+                cand &= cand - 1;
+                // exact score: k-ascending fp32 fma chain (== v_mfma_f32_32x32x2_f32, == oracle)
+                const float *qrow = tb + c * LD;
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < K; e += 4) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
+                    s = __builtin_fmaf(pf[e], qv[0], s); s = __builtin_fmaf(pf[e + 1], qv[1], s);
+                    s = __builtin_fmaf(pf[e + 2], qv[2], s); s = __builtin_fmaf(pf[e + 3], qv[3], s);
+                }
+                ++rescored;
+                if (S.cnt == N && !(S.thr < s)) continue;
+                scan_push(S, N, s, (int32_t)(it0 + c));
+            }
+            thr_w[r] = S.thr;
+        }
+        if (t + 1 < ntiles) commit(cur ^ 1);
+        nu = nu_next;
+        __syncthreads();
+    }
+
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
+}
+
+template <int K2>
+inline void launch_scan_f32(const ScanArgs &a, hipStream_t stream, dim3 grid, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<K2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_topn_scan<K2>, grid, dim3(256), lds, stream, a);
+}
+template <int K16>
+inline void launch_scan_bf16(const ScanArgs &a, hipStream_t stream, dim3 grid, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan_bf16<K16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_topn_scan_bf16<K16>, grid, dim3(256), lds, stream, a);
+}
+
+// force_f32 != 0: always the exact-f32-MFMA kernel.  Otherwise k in {16,32,64,128} takes the bf16
+// pre-filter kernel (identical results), anything else the f32 kernel.  Returns 1 if bf16 was used.
+inline int launch_scan(const ScanArgs &a, hipStream_t stream, int force_f32) {
+    if (a.k > 128 || a.N > 100) return -1;
+    const dim3 grid((unsigned)((a.nu + kScanWaves * 32 - 1) / (kScanWaves * 32)));
+    if (!force_f32 && (a.k == 16 || a.k == 32 || a.k == 64 || a.k == 128)) {
+        const size_t lds = scan_bf16_lds_bytes(a.k, a.N);
+        switch (a.k) {
+            case 16: launch_scan_bf16<1>(a, stream, grid, lds); break;
+            case 32: launch_scan_bf16<2>(a, stream, grid, lds); break;
+            case 64: launch_scan_bf16<4>(a, stream, grid, lds); break;
+            default: launch_scan_bf16<8>(a, stream, grid, lds); break;
+        }
+        return 1;
+    }
     const int kp = a.k + (a.k & 1);
     const int K2 = kp / 2 <= 8 ? 8 : kp / 2 <= 16 ? 16 : kp / 2 <= 32 ? 32 : 64;
-    if (kp / 2 > 64 || a.N > 100) return -1;
     const size_t lds = scan_lds_bytes(K2, a.N);
-    const dim3 grid((unsigned)((a.nu + kScanWaves * 32 - 1) / (kScanWaves * 32))), block(256);
     switch (K2) {
-        case 8:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_topn_scan<8>, grid, block, lds, stream, a); break;
-        case 16:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_topn_scan<16>, grid, block, lds, stream, a); break;
-        case 32:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_topn_scan<32>, grid, block, lds, stream, a); break;
-        default:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_topn_scan<64>, grid, block, lds, stream, a); break;
+        case 8: launch_scan_f32<8>(a, stream, grid, lds); break;
+        case 16: launch_scan_f32<16>(a, stream, grid, lds); break;
+        case 32: launch_scan_f32<32>(a, stream, grid, lds); break;
+        default: launch_scan_f32<64>(a, stream, grid, lds); break;
     }
     return 0;
 }

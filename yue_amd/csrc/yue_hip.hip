@@ -70,9 +70,13 @@ struct yue_ctx {
     // scoring scratch
     DevBuf<int32_t> s_users, s_ids, s_mask_idx, s_flags;
     DevBuf<int64_t> s_mask_ptr;
-    DevBuf<float> s_scores, s_row;
+    DevBuf<float> s_scores, s_row, s_norms;
     double scan_ms = 0.0;
-    int64_t scan_events = 0;
+    int64_t scan_events = 0, scan_rescored = 0;
+    int scan_used_bf16 = 0;
+    // options (yue_set_option)
+    int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
+    int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     // kernel timing
     int timing_stride = 0;
     int64_t launch_counter = 0;
@@ -114,10 +118,9 @@ void launch_level(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1) {
     }
 }
 
-int tpw_of(int k) {
-    int tpw = kr_of(k) == 4 ? 4 : 8;
-    if (const char *ev = std::getenv("YUE_TPW")) tpw = std::atoi(ev);      // tuning knob
-    return tpw;
+int tpw_of(const yue_ctx *c) {
+    if (c->opt_round_tpw) return c->opt_round_tpw;
+    return kr_of(c->k) == 4 ? 4 : 8;
 }
 
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
@@ -130,7 +133,7 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
     ra.cnt_cur = cnt[parity]; ra.cnt_next = cnt[parity ^ 1]; ra.cntp_cur = cntp[parity]; ra.cntp_next = cntp[parity ^ 1];
     ra.sample_next = sample_next; ra.apply_p = apply_p;
     ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
-    const int tpw = tpw_of(c->k);
+    const int tpw = tpw_of(c);
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
     const int64_t blocks = ra.prep_blocks + (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
@@ -260,7 +263,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
-    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release();
+    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
     return YUE_OK;
@@ -509,11 +512,26 @@ int yue_get_kernel_timing(yue_ctx *c, double *total_ms, int64_t *launches, int64
     return YUE_OK;
 }
 
-int yue_get_scan_stats(yue_ctx *c, double *kernel_ms, int64_t *events) {
+int yue_get_scan_stats(yue_ctx *c, double *kernel_ms, int64_t *events, int64_t *rescored, int *used_bf16) {
     if (!c) return fail(YUE_ERR_ARG, "null context");
     if (kernel_ms) *kernel_ms = c->scan_ms;
     if (events) *events = c->scan_events;
+    if (rescored) *rescored = c->scan_rescored;
+    if (used_bf16) *used_bf16 = c->scan_used_bf16;
     return YUE_OK;
+}
+
+int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return fail(YUE_ERR_ARG, "yue_set_option: null argument");
+    const std::string key(name);
+    if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
+    if (key == "round_tpw") {
+        if (value != 0 && value != 2 && value != 4 && value != 8) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw must be 0, 2, 4 or 8");
+        if (value == 8 && kr_of(c->k) == 4) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw 8 needs k <= 128");
+        c->opt_round_tpw = (int)value;
+        return YUE_OK;
+    }
+    return fail(YUE_ERR_ARG, "yue_set_option: unknown option " + key);
 }
 
 int yue_scores(yue_ctx *c, int32_t user, float *out_n) {
@@ -540,7 +558,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     if (nu == 0) return YUE_OK;
     HIPCHK(hipSetDevice(c->device));
     for (int64_t t = 0; t < nu; ++t) if (users[t] < 0 || users[t] >= c->m) return fail(YUE_ERR_ARG, "yue_topn_scan: user id out of range");
-    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(2));
+    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4));
     HIPCHK(hipMemcpyAsync(c->s_users.p, users, nu * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     yue::ScanArgs sa{};
     sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
@@ -560,15 +578,19 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     } else {
         sa.mask_ptr = c->indptr.p; sa.mask_idx = c->indices.p; sa.mask_by_user = 1;
     }
-    HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 2 * sizeof(int32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
+    HIPCHK(c->s_norms.resize(c->n));
+    hipLaunchKernelGGL(yue::k_row_norms, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
+    sa.item_norms = c->s_norms.p;
     hipEvent_t t0, t1;
     HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
     HIPCHK(hipEventRecord(t0, c->stream));
-    int rc = yue::launch_scan(sa, c->stream);
+    int rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32);
     HIPCHK(hipEventRecord(t1, c->stream));
-    if (rc) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination");
+    if (rc < 0) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination");
+    c->scan_used_bf16 = rc;
     HIPCHK(hipGetLastError());
-    int32_t flags[2];
+    int32_t flags[4];
     HIPCHK(hipMemcpyAsync(out_ids, c->s_ids.p, nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out_scores, c->s_scores.p, nu * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(flags, c->s_flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
@@ -578,6 +600,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     c->scan_ms = ms;
     c->scan_events = flags[1];
+    c->scan_rescored = flags[2];
     if (flags[0]) return fail(YUE_ERR_FEW_ITEMS, "a user has fewer than N candidate items (the reference raises IndexError, base/IterativeRecommender.py:126)");
     return YUE_OK;
 }
