@@ -86,6 +86,8 @@ struct yue_ctx {
     // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    hipStream_t comm_stream = nullptr;   // all-reduce + user-row apply run here, beside the next rounds
+    hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
 };
 
 namespace {
@@ -257,6 +259,9 @@ int yue_ctx_destroy(yue_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+    if (c->ev_rounds) (void)hipEventDestroy(c->ev_rounds);
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
@@ -473,12 +478,20 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
             if ((r + 1) % group != 0 && r + 1 != R) return YUE_OK;
             const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
             const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
-            NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->stream));
-            hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->stream,
+            // The collective and the apply of this group's user rows run on the communication stream
+            // while the compute stream goes on with the next group's rounds: those touch other users'
+            // rows of P and dP only (a user never straddles groups), and item rows are rank-local.
+            HIPCHK(hipEventRecord(c->ev_rounds, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0));
+            NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream));
+            hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->comm_stream,
                                c->P.p, c->dP.p, first, count);
             return YUE_OK;
         };
         if ((rc = run_rounds(c, a, bounds, 1, 0, after))) return rc;
+        // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
+        HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     }
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
@@ -621,6 +634,9 @@ int yue_comm_init(yue_ctx *c, const void *id128, int rank, int nranks) {
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     c->rank = rank; c->nranks = nranks;
     return YUE_OK;
 }
