@@ -14,11 +14,21 @@ from util import csr_from_events, gj, gz
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_config_matches_reference():
+def _conf_text(overrides=None, extra=None):
+    """key=value lines of the reference's BPR.conf as captured in the golden (data, not a copy of the file)."""
+    kv = dict(gj('g1_config.json')['bpr_conf'])
+    kv.update(overrides or {})
+    kv.update(extra or {})
+    return '\n'.join('%s=%s' % item for item in kv.items()) + '\n'
+
+
+def test_config_matches_reference(tmp_path):
     g = gj('g1_config.json')
-    conf = Config(os.path.join(ROOT, 'yue_amd', 'config', 'BPR.conf'))
+    path = tmp_path / 'BPR.conf'
+    path.write_text(_conf_text(extra={'bpr.hip': '-mode replay -gpu 0'}) + 'a malformed line\n\n')
+    conf = Config(str(path))
     ours = dict(conf.config)
-    assert ours.pop('bpr.hip')                      # our only extra key; everything else is the reference's file
+    assert ours.pop('bpr.hip') == '-mode replay -gpu 0'     # our optional key; the rest parses as in the reference
     assert ours == g['bpr_conf']
     for case in g['lineconfig']:
         lc = LineConfig(case['line'])
@@ -31,10 +41,8 @@ def _c1_conf(tmp_path, k=10, iters=1, topn='5,10', extra=''):
     log = tmp_path / 'log.txt'
     if not log.exists():
         synth.write_text_log(str(log), 1000, 1000, 20)
-    text = open(os.path.join(ROOT, 'yue_amd', 'config', 'BPR.conf')).read()
-    text = text.replace('record=./dataset/log.txt', 'record=' + str(log))
-    text = text.replace('num.factors=10', 'num.factors=%d' % k).replace('num.max.iter=1', 'num.max.iter=%d' % iters)
-    text = text.replace('-topN 5,10', '-topN ' + topn).replace('-dir ./results/', '-dir ' + str(tmp_path / 'results') + '/')
+    text = _conf_text({'record': str(log), 'num.factors': str(k), 'num.max.iter': str(iters), 'item.ranking': '-topN ' + topn,
+                       'output.setup': 'on -dir ' + str(tmp_path / 'results') + '/'}, {'bpr.hip': '-mode replay -gpu 0'})
     p = tmp_path / ('c1_%d_%d.conf' % (k, iters))
     p.write_text(text + extra)
     return Config(str(p))

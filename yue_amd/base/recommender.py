@@ -1,8 +1,17 @@
-"""Plugin template: same lifecycle and hooks as the reference's base/recommender.py.
+"""Plugin template of the Yue driver, hosted for the MI355X BPR path.
 
-execute(): readConfiguration -> printAlgorConfig (fold [1]) -> loadModel | initModel + buildModel
--> evalRanking -> saveModel, returns self.measure (reference base/recommender.py:152-174).
-Constructor signature of every plugin: (conf, trainingSet=None, testSet=None, fold='[1]').
+What a plugin is (contract kept from the reference, base/recommender.py:10-174, so that an existing
+recommender class drops in):
+
+  constructor   ``(conf, trainingSet=None, testSet=None, fold='[1]')``; builds ``self.data`` (Record),
+                reads ``evaluation.setup`` (``-target`` type, ``-cold N`` and ``-sample`` test filters)
+  hooks         ``readConfiguration  printAlgorConfig  initModel  buildModel  saveModel  loadModel
+                predict  evalRanking`` -- subclasses override what they need
+  execute()     readConfiguration -> printAlgorConfig (fold [1] only) -> loadModel | initModel +
+                buildModel -> evalRanking -> [saveModel]; returns ``self.measure`` (list of strings)
+
+Ours on top of that: ``_top_list`` / ``_write_results`` (shared by the factor models' GPU ranking)
+and ``test_user_names``.
 """
 from collections import defaultdict
 from os.path import abspath
@@ -13,52 +22,63 @@ from ..evaluation.measure import Measure
 from ..tool.config import LineConfig
 from ..tool.file import FileIO
 
+_RULE = '=' * 80
+
 
 class Recommender(object):
     def __init__(self, conf, trainingSet=None, testSet=None, fold='[1]'):
         self.config = conf
-        self.isSaveModel = False
-        self.isLoadModel = False
-        self.isOutput = True
-        self.data = Record(self.config, trainingSet, testSet)
         self.foldInfo = fold
-        self.evalConfig = LineConfig(self.config['evaluation.setup'])
+        self.isSaveModel = self.isLoadModel = False
+        self.isOutput = True
+        self.data = Record(conf, trainingSet, testSet)
+        self.evalConfig = LineConfig(conf['evaluation.setup'])
         self.recType = self.evalConfig['-target'] if self.evalConfig.contains('-target') else 'track'
         if self.evalConfig.contains('-cold'):
-            self._keep_cold_items(int(self.evalConfig['-cold']))
+            self._restrict_to_cold_items(int(self.evalConfig['-cold']))
         if self.evalConfig.contains('-sample'):
-            users = list(self.data.testSet.keys())
-            for user in users[:int(len(users) * 0.9)]:
-                del self.data.testSet[user]
+            self._keep_last_tenth_of_test_users()
 
-    def _keep_cold_items(self, threshold):
-        # reference base/recommender.py:22-39: drop test items with more than `threshold` training plays
-        drop = defaultdict(list)
-        for user in self.data.testSet:
+    # ---- test-set filters -----------------------------------------------------------------
+    def _restrict_to_cold_items(self, max_plays):
+        """``-cold N``: test items played more than N times in training are dropped
+        (only for users that also have training records); users left without items go too."""
+        doomed = defaultdict(list)
+        for user, wanted in self.data.testSet.items():
             if user in self.data.userRecord:
-                for item in self.data.testSet[user]:
-                    if len(self.data.trackRecord[item]) > threshold:
-                        drop[user].append(item)
-        for user, items in drop.items():
+                doomed[user] = [item for item in wanted if len(self.data.trackRecord[item]) > max_plays]
+        for user, items in doomed.items():
             for item in items:
                 del self.data.testSet[user][item]
             if not self.data.testSet[user]:
                 del self.data.testSet[user]
 
+    def _keep_last_tenth_of_test_users(self):
+        """``-sample``: the first 90 % of the test users (dict order) are not evaluated."""
+        names = self.test_user_names()
+        for user in names[:int(len(names) * 0.9)]:
+            del self.data.testSet[user]
+
+    def test_user_names(self):
+        return list(self.data.testSet.keys())
+
+    # ---- hooks ----------------------------------------------------------------------------
     def readConfiguration(self):
-        self.algorName = self.config['recommender']
-        self.output = LineConfig(self.config['output.setup'])
+        conf = self.config
+        self.algorName = conf['recommender']
+        self.output = LineConfig(conf['output.setup'])
         self.isOutput = self.output.isMainOn()
-        self.ranking = LineConfig(self.config['item.ranking'])
+        self.ranking = LineConfig(conf['item.ranking'])
 
     def printAlgorConfig(self):
         "show algorithm's configuration"
-        print('Algorithm:', self.config['recommender'])
-        print('Training set:', abspath(self.config['record']))
+        lines = [('Algorithm:', self.config['recommender']), ('Training set:', abspath(self.config['record']))]
         if self.evalConfig.contains('-testSet'):
-            print('Test set:', abspath(self.evalConfig.getOption('-testSet')))
+            lines.append(('Test set:', abspath(self.evalConfig.getOption('-testSet'))))
+        for label, value in lines:
+            print(label, value)
         self.data.printTrainingSize()
-        print('=' * 80)
+        print(_RULE)
 
     def initModel(self):
         pass
@@ -76,70 +96,44 @@ class Recommender(object):
     def predict(self, user):
         return []
 
+    def evalRanking(self):
+        """Ranking evaluation.  The reference's base class ranks recommenders whose predict() returns
+        an ordered item list (base/recommender.py:85-150); none of those is part of this build, the
+        factor models override this hook (IterativeRecommender.evalRanking)."""
+        raise NotImplementedError('list-returning recommenders are outside the MI355X BPR build')
+
+    # ---- shared by the ranking evaluations --------------------------------------------------
     def _top_list(self):
-        top = [int(num) for num in self.ranking['-topN'].split(',')]
-        return top
+        return [int(num) for num in self.ranking['-topN'].split(',')]
 
     def _write_results(self, res, recList, top):
+        """Lists file (when output is on), measure file, ``self.measure`` and the final print --
+        file names as in the reference: ``<Algo>@<time>-top-<N>items<fold>.txt`` / ``-measure<fold>.txt``."""
         stamp = strftime("%Y-%m-%d %H-%M-%S", localtime(time()))
         outDir = self.output['-dir']
+        prefix = self.config['recommender'] + '@' + stamp
         if self.isOutput:
-            fileName = ''
-            if self.ranking.contains('-topN'):
-                fileName = self.config['recommender'] + '@' + stamp + '-top-' + self.ranking['-topN'] + 'items' + self.foldInfo + '.txt'
-            FileIO.writeFile(outDir, fileName, res)
+            listing = prefix + '-top-' + self.ranking['-topN'] + 'items' + self.foldInfo + '.txt' if self.ranking.contains('-topN') else ''
+            FileIO.writeFile(outDir, listing, res)
             print('The result has been output to ', abspath(outDir), '.')
-        fileName = self.config['recommender'] + '@' + stamp + '-measure' + self.foldInfo + '.txt'
         self.measure = Measure.rankingMeasure(self.data.testSet, recList, top, self.data.getSize(self.recType))
-        FileIO.writeFile(outDir, fileName, self.measure)
+        FileIO.writeFile(outDir, prefix + '-measure' + self.foldInfo + '.txt', self.measure)
         print('The result of %s %s:\n%s' % (self.algorName, self.foldInfo, ''.join(self.measure)))
 
-    def evalRanking(self):
-        """Generic form for recommenders whose predict() returns an ordered item list
-        (reference base/recommender.py:85-150)."""
-        top = self._top_list()
-        N = int(top[-1])
-        if N > 100 or N < 0:
-            print('N can not be larger than 100! It has been reassigned with 10')
-            N = 10
-        res = ['userId: recommendations in (itemId, ranking score) pairs, * means the item matches, $ means the unpop item\n']
-        recList = {}
-        userCount = len(self.data.testSet)
-        for i, user in enumerate(self.data.testSet):
-            ranked = self.predict(user) if user in self.data.userRecord else ['0'] * N
-            position = {}
-            for k, item in enumerate(ranked):
-                position[item] = k
-            for event in self.data.userRecord[user]:
-                position.pop(event[self.recType], None)
-            recList[user] = [item for item, _ in sorted(position.items(), key=lambda d: d[1])][:N]
-            if i % 100 == 0:
-                print(self.algorName, self.foldInfo, 'progress:' + str(i) + '/' + str(userCount))
-            line = user + ':'
-            for item in recList[user]:
-                if item in self.data.testSet[user]:
-                    line += '*'
-                if item in self.data.PopTrack:
-                    line += '$'
-                line += item + ','
-            res.append(line + '\n')
-        self._write_results(res, recList, top)
-
+    # ---- lifecycle ------------------------------------------------------------------------
     def execute(self):
+        fold = self.foldInfo
         self.readConfiguration()
-        if self.foldInfo == '[1]':
+        if fold == '[1]':
             self.printAlgorConfig()
         if self.isLoadModel:
-            print('Loading model %s...' % (self.foldInfo))
-            self.loadModel()
+            steps = [('Loading model %s...', self.loadModel)]
         else:
-            print('Initializing model %s...' % (self.foldInfo))
-            self.initModel()
-            print('Building Model %s...' % (self.foldInfo))
-            self.buildModel()
-        print('Predicting %s...' % (self.foldInfo))
-        self.evalRanking()
+            steps = [('Initializing model %s...', self.initModel), ('Building Model %s...', self.buildModel)]
+        steps.append(('Predicting %s...', self.evalRanking))
         if self.isSaveModel:
-            print('Saving model %s...' % (self.foldInfo))
-            self.saveModel()
+            steps.append(('Saving model %s...', self.saveModel))
+        for message, hook in steps:
+            print(message % fold)
+            hook()
         return self.measure

@@ -1,11 +1,9 @@
 """Menu front end (reference main.py:7-80).  `python -m yue_amd.main` from the repository root."""
-import os
 import time
 
 from .tool.config import Config
 from .yue import Yue
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
 MENU = {'1': 'BPR'}
 
 
@@ -21,7 +19,7 @@ def main():
     if order not in MENU:
         print('Error num!')
         exit(-1)
-    conf = Config(os.path.join(_HERE, 'config', MENU[order] + '.conf'))
+    conf = Config('./config/' + MENU[order] + '.conf')      # the user's own file, as in the reference (main.py:36-37)
     Yue(conf).execute()
     print("Run time: %f s" % (time.time() - start))
 

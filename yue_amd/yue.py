@@ -6,11 +6,27 @@ yue_amd.recommender are importable (BPR in this build).
 """
 import importlib
 from multiprocessing import Manager, Process
+from random import random
 from time import localtime, strftime, time
 
 from .tool.config import LineConfig
-from .tool.dataSplit import DataSplit
 from .tool.file import FileIO
+
+
+def _holdout(events, test_ratio):
+    """-ap: every event goes to the test side with probability test_ratio (reference tool/dataSplit.py:9-23)."""
+    if not 0 < test_ratio < 1:
+        test_ratio = 0.3
+    sides = ([], [])
+    for event in events:
+        sides[random() < test_ratio].append(event)
+    return sides
+
+
+def _folds(events, k):
+    """-cv: fold f tests the events whose position is f modulo k (reference tool/dataSplit.py:26-37)."""
+    for f in range(k):
+        yield events[:0] + [e for pos, e in enumerate(events) if pos % k != f], events[f::k]
 
 
 def _find_recommender(name):
@@ -51,7 +67,7 @@ class Yue(object):
             self.trainingData = load(config['record'])
             self.testData = load(self.evaluation['-testSet'])
         elif self.evaluation.contains('-ap'):
-            self.trainingData, self.testData = DataSplit.dataSplit(load(config['record']), test_ratio=float(self.evaluation['-ap']))
+            self.trainingData, self.testData = _holdout(load(config['record']), float(self.evaluation['-ap']))
         elif self.evaluation.contains('-byTime'):
             self.trainingData = load(config['record'])      # Record splits per user by time
             self.testData = []
@@ -69,7 +85,7 @@ class Yue(object):
             k = 3
         shared = Manager().dict()
         tasks = []
-        for order, (train, test) in enumerate(DataSplit.crossValidation(self.trainingData, k), 1):
+        for order, (train, test) in enumerate(_folds(self.trainingData, k), 1):
             # the HIP context is created inside the child (first device call), never before the fork
             tasks.append(Process(target=run, args=(shared, cls(self.config, train, test, '[' + str(order) + ']'), order)))
         parallel = self.evaluation.contains('-p')
