@@ -38,8 +38,11 @@ struct TrainArgs {
 struct RoundArgs {
     int64_t e_begin, e_end;      // events updated by this launch
     int64_t n_begin, n_end;      // events of the NEXT round: negatives drawn and row touches counted here
-    uint32_t *cnt_cur;           // touches per item row in [e_begin, e_end)   (filled by the previous launch)
-    uint32_t *cnt_next;          // touches per item row in [n_begin, n_end)
+    // Item-row touch counters, one 64-bit word per row: high half = touches in the round (fixed while
+    // the round runs: decides in-place store vs atomic path), low half = touches not yet retired
+    // (decremented by the last-arriver protocol).  A late wave must never see a decremented total.
+    unsigned long long *cnt_cur;     // round [e_begin, e_end)   (filled by the previous launch)
+    unsigned long long *cnt_next;    // round [n_begin, n_end)
     uint32_t *cntp_cur;          // user-row flushes (runs of equal users inside a wave's batch) in this round
     uint32_t *cntp_next;         // ... in the next round
     int apply_p;                 // 1: user rows are finished in this launch; 0: dP is left for the all-reduce
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 #define YUE_BSTORE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 0)
 #define YUE_BATOMIC(val, rs, vo, so) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((val), (rs), (vo), (so), 0)
 constexpr unsigned kOobOffset = 0x80000000u;
+constexpr unsigned long long kTouch = 0x100000001ull;      // +1 touch in both halves of a counter word
 constexpr int kRsrcFlags = 0x00020000;
 
 template <int KR, int TPW>
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
             int32_t j;
             if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
             else j = a.ev_j[e];
-            if (j >= 0) { atomicAdd(ra.cnt_next + i, 1u); atomicAdd(ra.cnt_next + j, 1u); }
+            if (j >= 0) { atomicAdd(ra.cnt_next + i, kTouch); atomicAdd(ra.cnt_next + j, kTouch); }
             if (ra.apply_p) {      // one flush per run of equal users inside a TPW-aligned batch
                 const int32_t u = a.ev_u[e];
                 if ((e - ra.n_begin) % TPW == 0 || a.ev_u[e - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
@@ -219,12 +223,12 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
     if (base >= ra.e_end) return;
 
     int u = 0, i = 0, j = -1;
-    uint32_t ci = 0, cj = 0;
+    uint32_t ci = 0, cj = 0;             // touches of my rows in this round (the immutable half)
     if (lane < TPW && base + lane < ra.e_end) {
         u = a.ev_u[base + lane];
         i = a.ev_i[base + lane];
         j = a.ev_j[base + lane];
-        if (j >= 0) { ci = ra.cnt_cur[i]; cj = ra.cnt_cur[j]; }
+        if (j >= 0) { ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32); }
     }
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = k * 4u;
@@ -300,9 +304,9 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
                 if (uniq_j) YUE_BSTORE(o.qj2, rsQ, vo[r], oj[t]); else YUE_BATOMIC(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
                 dp[r] += o.p2 - p[t][r];
             }
-            if (lane == 0) {                             // sole toucher: reset the count here
-                if (uniq_i) ra.cnt_cur[ri_[t]] = 0u;
-                if (uniq_j) ra.cnt_cur[rj_[t]] = 0u;
+            if (lane == 0) {                             // sole toucher: reset the counter here
+                if (uniq_i) ra.cnt_cur[ri_[t]] = 0ull;
+                if (uniq_j) ra.cnt_cur[rj_[t]] = 0ull;
             }
         }
         // end of a run of equal users (or of the batch): flush the summed P[u] differences
@@ -329,32 +333,50 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bool last_i = false, last_j = false, last_p = false;
     if (lane < TPW && j >= 0) {
-        if (ci != 1u) last_i = atomicSub(ra.cnt_cur + i, 1u) == 1u;
-        if (cj != 1u) last_j = atomicSub(ra.cnt_cur + j, 1u) == 1u;
+        if (ci != 1u) last_i = (uint32_t)atomicAdd(ra.cnt_cur + i, ~0ull) == 1u;     // -1 on the low half
+        if (cj != 1u) last_j = (uint32_t)atomicAdd(ra.cnt_cur + j, ~0ull) == 1u;
     }
     if (ra.apply_p && lane < nruns) last_p = atomicSub(ra.cntp_cur + run_u, 1u) == 1u;
-    unsigned long long mi = __ballot(last_i), mj = __ballot(last_j), mp = __ballot(last_p);
-    while (mi | mj) {
-        const bool from_i = mi != 0;
-        const int b = __ffsll((long long)(from_i ? mi : mj)) - 1;
-        if (from_i) mi &= mi - 1; else mj &= mj - 1;
-        const unsigned row = (unsigned)__builtin_amdgcn_readlane(from_i ? i : j, b);
-        const uint64_t o = (uint64_t)row * k;
+    // winners: bits [0,TPW) = item row i of that lane, [TPW,2*TPW) = row j, [2*TPW,3*TPW) = user run
+    unsigned long long win = (__ballot(last_i) & ((1ull << TPW) - 1)) | ((__ballot(last_j) & ((1ull << TPW) - 1)) << TPW) |
+                             ((__ballot(last_p) & ((1ull << TPW) - 1)) << (2 * TPW));
+    while (win) {
+        // up to four rows per pass: all swaps and row loads are issued before the first store
+        float *xp[4], *dx[4];
+        bool act[4];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) {
-            const unsigned e = 64u * r + lane;
-            if (e < k) { const float d = atomicExch(a.dQ + o + e, 0.0f); a.Q[o + e] += d; }
+        for (int sl = 0; sl < 4; ++sl) {
+            act[sl] = win != 0;
+            const int b = act[sl] ? __ffsll((long long)win) - 1 : 0;
+            if (act[sl]) win &= win - 1;
+            const int src = b % TPW;
+            const unsigned row = b < TPW ? (unsigned)__builtin_amdgcn_readlane(i, src)
+                                 : b < 2 * TPW ? (unsigned)__builtin_amdgcn_readlane(j, src)
+                                               : (unsigned)__builtin_amdgcn_readlane((int)run_u, src);
+            const uint64_t o = (uint64_t)row * k;
+            xp[sl] = (b < 2 * TPW ? a.Q : a.P) + o;
+            dx[sl] = (b < 2 * TPW ? a.dQ : a.dP) + o;
+            if (act[sl] && b < 2 * TPW && lane == 0) ra.cnt_cur[row] = 0ull;      // every touch retired: clear the word
         }
-    }
-    while (mp) {
-        const int b = __ffsll((long long)mp) - 1;
-        mp &= mp - 1;
-        const uint64_t o = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)run_u, b) * k;
+        float d[4][KR], x[4][KR];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) {
-            const unsigned e = 64u * r + lane;
-            if (e < k) { const float d = atomicExch(a.dP + o + e, 0.0f); a.P[o + e] += d; }
-        }
+        for (int sl = 0; sl < 4; ++sl)
+            if (act[sl]) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const unsigned e = 64u * r + lane;
+                    if (e < k) { d[sl][r] = atomicExch(dx[sl] + e, 0.0f); x[sl][r] = xp[sl][e]; }
+                }
+            }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (act[sl]) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const unsigned e = 64u * r + lane;
+                    if (e < k) xp[sl][e] = x[sl][r] + d[sl][r];
+                }
+            }
     }
 #pragma unroll
     for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
