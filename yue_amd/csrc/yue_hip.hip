@@ -123,7 +123,7 @@ void launch_level(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1) {
 
 int tpw_of(const yue_ctx *c) {
     if (c->opt_round_tpw) return c->opt_round_tpw;
-    return 4;      // measured on C3: 4 events per wave beats 8 by ~2.5 % (more waves in flight, shorter tails)
+    return kr_of(c->k) == 4 ? 4 : 8;      // measured on C3 (k=128): 8 events per wave 53.9 ms/epoch, 4 -> 58.7 ms
 }
 
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
