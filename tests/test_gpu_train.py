@@ -95,6 +95,34 @@ def test_rounds_match_oracle(dev, orc, tag, W):
     assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
 
 
+def test_rounds_with_arbitrary_user_order_and_wide_factors(dev, orc):
+    # explicit triplets whose users are NOT grouped (runs of equal users are short and repeat), k = 200
+    # (four registers per lane and row, the 4-events-per-wave instance), skipped triplets, ragged rounds
+    rs = np.random.RandomState(21)
+    m, n, k, T = 700, 900, 200, 20000
+    P0 = rs.rand(m, k).astype(np.float32) / 10
+    Q0 = rs.rand(n, k).astype(np.float32) / 10
+    u = rs.randint(0, m, size=T).astype(np.int32)
+    u[::3] = u[1::3][:len(u[::3])]                      # some consecutive repeats
+    i = rs.randint(0, n, size=T).astype(np.int32)
+    j = ((i + 1 + rs.randint(0, n - 1, size=T)) % n).astype(np.int32)
+    j[rs.rand(T) < 0.01] = -1
+    rp = np.array([0, 1, 2, 50, 51, 4000, 4003, 12345, T], np.int64)
+    dev.set_factors(P0, Q0)
+    nll = dev.bpr_rounds(u, i, j, rp, 0.03, 0.02, 0.01)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_rounds(Po, Qo, u, i, j, rp, 0.03, 0.02, 0.01)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    # the same stream replayed exactly (sequential semantics) on the wide factors
+    dev.set_factors(P0, Q0)
+    nll = dev.bpr_replay(u[:3000], i[:3000], j[:3000], 0.03, 0.02, 0.01)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_sequential(Po, Qo, u[:3000], i[:3000], j[:3000], 0.03, 0.02, 0.01)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+
+
 def test_rounds_of_one_reduce_to_the_reference_loop(dev):
     # S-round with one triplet per round is the sequential loop: compare with the reference's output
     z, iters, E = _golden('d2_k64_e1')

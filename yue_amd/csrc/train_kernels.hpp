@@ -236,8 +236,14 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
 #pragma unroll
     for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; vo[r] = e < k ? e * 4u : kOobOffset; }
 
-    // users of one batch are neighbours: P / dP are addressed relative to the batch's first user
-    const unsigned u0 = (unsigned)__builtin_amdgcn_readlane(u, 0);
+    // users of one batch are neighbours (user-major events): P / dP are addressed relative to the
+    // batch's smallest user id, so the 31-bit byte offsets hold for any number of users
+    unsigned u0 = 0xffffffffu;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const unsigned ut = (unsigned)__builtin_amdgcn_readlane(u, t);
+        if (base + t < ra.e_end && ut < u0) u0 = ut;
+    }
     const uint64_t qbytes = (uint64_t)a.n * row_bytes, pbytes = (uint64_t)(a.m - u0) * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
     const int prec = (int)(pbytes < 0x7fffffffull ? pbytes : 0x7fffffffull);
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
         ok[t] = tj >= 0;                                 // no event / sampler gave up: nothing is written
         rj_[t] = ok[t] ? (unsigned)tj : 0u;
         oi[t] = ri_[t] * row_bytes; oj[t] = rj_[t] * row_bytes;
-        ou[t] = (ok[t] ? ru_[t] - u0 : 0u) * row_bytes;
+        ou[t] = (base + t < ra.e_end ? ru_[t] - u0 : 0u) * row_bytes;
 #pragma unroll
         for (int r = 0; r < KR; ++r) { qi[t][r] = YUE_BLOAD(rsQ, vo[r], oi[t]); qj[t][r] = YUE_BLOAD(rsQ, vo[r], oj[t]); }
     }

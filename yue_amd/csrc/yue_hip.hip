@@ -409,6 +409,16 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     const int64_t T = round_ptr[n_rounds];
     if (round_ptr[0] != 0) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr[0] must be 0");
     for (int64_t r = 0; r < n_rounds; ++r) if (round_ptr[r + 1] < round_ptr[r]) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr must be non-decreasing");
+    if (c->m * (int64_t)c->k * 4 >= (1ll << 31)) {
+        // the round kernel addresses P relative to the smallest user of a wave's batch with 31-bit offsets
+        const int tpw = tpw_of(c);
+        for (int64_t r = 0; r < n_rounds; ++r)
+            for (int64_t b = round_ptr[r]; b < round_ptr[r + 1]; b += tpw) {
+                int32_t lo = u[b], hi = u[b];
+                for (int64_t t = b; t < std::min(round_ptr[r + 1], b + tpw); ++t) { lo = std::min(lo, u[t]); hi = std::max(hi, u[t]); }
+                if ((int64_t)(hi - lo) * c->k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_bpr_rounds: users of neighbouring triplets are more than 2 GiB of factor rows apart; group the triplets by user");
+            }
+    }
     int rc = upload_triplets(c, u, i, j, T);
     if (rc) return rc;
     yue::TrainArgs a = make_args(c, lr, regU, regI);
