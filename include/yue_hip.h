@@ -115,9 +115,12 @@ int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_time
  * done behind the bf16 pre-filter, and whether the bf16 pre-filter kernel ran (k in 16/32/64/128). */
 int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t *rescored, int *used_bf16);
 
-/* Tuning / diagnostic knobs (results do not depend on them):
+/* Tuning / diagnostic knobs (results do not depend on the first two):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
- *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8 */
+ *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8
+ * Behaviour switch (off by default = the reference's behaviour):
+ *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
+ *               the reference's order-dependent overwrite-scan */
 int yue_set_option(yue_ctx *ctx, const char *name, int64_t value);
 
 /* Multi-GPU (one process per GPU, RCCL over xGMI).  Rank 0 creates the id, the caller ships

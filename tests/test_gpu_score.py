@@ -92,6 +92,27 @@ def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
     assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
 
 
+def test_true_topn_mode(dev, orc):
+    # a real top-N beside the reference's overwrite-scan (which is not one, F4)
+    for (m, n, k, N, quant) in [(100, 3000, 128, 20, False), (50, 700, 10, 10, False), (40, 600, 16, 10, True)]:
+        P, Q, indptr, indices = _rand_problem(m, n, k, 25, seed=n + N)
+        if quant:       # many equal scores: ties must keep the lower item id first
+            P, Q = np.round(P), np.round(Q)
+        dev.set_factors(P, Q)
+        users = np.arange(m, dtype=np.int32)
+        mp, mi = mask_rows(indptr, indices, users)
+        dev.set_option('topn_true', 1)
+        ids, sc = dev.topn_scan(users, N, mp, mi)
+        dev.set_option('topn_true', 0)
+        oid, osc, _ = orc.topn_true(P, Q, users, N, mp, mi)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+        for t in range(0, m, 7):                                # independent check with NumPy
+            s = orc.scores(P, Q, t).astype(np.float64)
+            s[mi[mp[t]:mp[t + 1]]] = -np.inf
+            order = np.lexsort((np.arange(n), -s))[:N]
+            assert np.array_equal(ids[t], order)
+
+
 def test_scan_with_ties_and_duplicates(dev, orc):
     # quantised factors give many equal scores: ties go after equals, stable seed order
     rs = np.random.RandomState(9)

@@ -64,12 +64,15 @@ class IterativeRecommender(Recommender):
         """HIP context of this process, created on first use (after any fork: yue.py -cv)."""
         if self.dev is None:
             from .._shim import Device
-            gpu = 0
+            gpu, true_topn = 0, False
             if self.config.contains('bpr.hip'):
                 opts = config.LineConfig(self.config['bpr.hip'])
                 if opts.contains('-gpu'):
                     gpu = int(opts['-gpu'])
+                true_topn = opts.contains('-topn') and opts['-topn'] == 'true'
             self.dev = Device(gpu)
+            if true_topn:        # a real top-N instead of the reference's overwrite-scan (off by default)
+                self.dev.set_option('topn_true', 1)
         return self.dev
 
     def _sync_factors_to_device(self):

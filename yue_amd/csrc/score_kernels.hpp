@@ -37,6 +37,7 @@ struct ScanArgs {
     float *out_scores;
     int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events, [2] exact re-scores (bf16 path)
     const float *item_norms;   // ||Q[i]||_2 per item (bf16 pre-filter margin); unused by the f32 kernel
+    int true_topn;             // 0: the reference's overwrite-scan (default); 1: a real top-N (ties: lower id first)
 };
 
 // Per-user selection state: N slots in LDS + the running threshold (the reference's state machine,
@@ -51,34 +52,46 @@ struct ScanState {
     int events;
 };
 
-__device__ __forceinline__ void scan_push(ScanState &S, int N, float s, int32_t item) {
+template <bool TRUE_TOPN>
+__device__ __forceinline__ void scan_push_t(ScanState &S, int N, float s, int32_t item) {
     ++S.events;
     if (S.cnt < N) {
         // seed phase (:107-112): keep id order in global scratch
-        S.g_sc[S.cnt] = s; S.g_id[S.cnt] = item;
+        if (!TRUE_TOPN) { S.g_sc[S.cnt] = s; S.g_id[S.cnt] = item; }
         // stable descending insertion (:114): later ids go after equal scores
         int p = S.cnt;
         while (p > 0 && S.st_a[p - 1] < s) { S.st_a[p] = S.st_a[p - 1]; S.st_id[p] = S.st_id[p - 1]; --p; }
         S.st_a[p] = s; S.st_id[p] = item;
         ++S.cnt;
         if (S.cnt == N) {
-            // the scan (:121-144) starts over from the first candidate
-            for (int q = 0; q < N; ++q) {
-                const float sq = S.g_sc[q];
-                if (S.st_a[N - 1] < sq) {
-                    int p2 = 0;
-                    while (S.st_a[p2] >= sq) ++p2;
-                    S.st_a[p2] = sq; S.st_id[p2] = S.g_id[q];
+            if (!TRUE_TOPN) {
+                // the scan (:121-144) starts over from the first candidate
+                for (int q = 0; q < N; ++q) {
+                    const float sq = S.g_sc[q];
+                    if (S.st_a[N - 1] < sq) {
+                        int p2 = 0;
+                        while (S.st_a[p2] >= sq) ++p2;
+                        S.st_a[p2] = sq; S.st_id[p2] = S.g_id[q];
+                    }
                 }
             }
             S.thr = S.st_a[N - 1];
         }
+    } else if (TRUE_TOPN) {
+        int p = N - 1;                         // real top-N: insert with shift, the smallest entry drops out
+        while (p > 0 && S.st_a[p - 1] < s) { S.st_a[p] = S.st_a[p - 1]; S.st_id[p] = S.st_id[p - 1]; --p; }
+        S.st_a[p] = s; S.st_id[p] = item;
+        S.thr = S.st_a[N - 1];
     } else {
         int p = 0;
         while (S.st_a[p] >= s) ++p;            // first slot strictly below s
         S.st_a[p] = s; S.st_id[p] = item;      // overwrite, no shift (:142-144)
         S.thr = S.st_a[N - 1];
     }
+}
+
+__device__ __forceinline__ void scan_push(ScanState &S, int N, float s, int32_t item, int true_topn) {
+    if (true_topn) scan_push_t<true>(S, N, s, item); else scan_push_t<false>(S, N, s, item);
 }
 
 __device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *flags) {
@@ -238,7 +251,7 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
                 cand &= cand - 1;
                 const float s = row[c];
                 if (S.cnt == N && !(S.thr < s)) continue;
-                scan_push(S, N, s, (int32_t)(it0 + c));
+                scan_push(S, N, s, (int32_t)(it0 + c), a.true_topn);
             }
             thr_w[r] = S.thr;
         }
@@ -404,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
                 }
                 ++rescored;
                 if (S.cnt == N && !(S.thr < s)) continue;
-                scan_push(S, N, s, (int32_t)(it0 + c));
+                scan_push(S, N, s, (int32_t)(it0 + c), a.true_topn);
             }
             thr_w[r] = S.thr;
         }

@@ -78,6 +78,7 @@ struct yue_ctx {
     // options (yue_set_option)
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
+    int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     // kernel timing
     int timing_stride = 0;
     int64_t launch_counter = 0;
@@ -550,6 +551,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail(YUE_ERR_ARG, "yue_set_option: null argument");
     const std::string key(name);
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
+    if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "round_tpw") {
         if (value != 0 && value != 2 && value != 4 && value != 8) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw must be 0, 2, 4 or 8");
         if (value == 8 && kr_of(c->k) == 4) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw 8 needs k <= 128");
@@ -588,6 +590,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     yue::ScanArgs sa{};
     sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
     sa.out_ids = c->s_ids.p; sa.out_scores = c->s_scores.p; sa.flags = c->s_flags.p;
+    sa.true_topn = c->opt_topn_true;
     if (mask_indptr) {
         const int64_t mnnz = mask_indptr[nu];
         for (int64_t t = 0; t < nu; ++t) {

@@ -13,6 +13,8 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
                                         throughput mode: counter-based sampler fused into the
                                         update kernel, S-round semantics.
   -gpu N                                HIP device ordinal.
+  -topn true                            evalRanking returns a real top-N (descending, ties: lower item id)
+                                        instead of the reference's order-dependent overwrite-scan.
 """
 from random import choice
 
