@@ -36,7 +36,7 @@ struct ScanArgs {
     int32_t *out_ids;
     float *out_scores;
     int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events, [2] exact re-scores (bf16 path)
-    const float *item_norms;   // ||Q[i]||_2 per item (bf16 pre-filter margin); unused by the f32 kernel
+    const float *tile_norm_max; // max ||Q[i]||_2 over each tile of 32 items (bf16 pre-filter margin); unused by the f32 kernel
     int true_topn;             // 0: the reference's overwrite-scan (default); 1: a real top-N (ties: lower id first)
 };
 
@@ -69,8 +69,8 @@ __device__ __forceinline__ void scan_push_t(ScanState &S, int N, float s, int32_
                 for (int q = 0; q < N; ++q) {
                     const float sq = S.g_sc[q];
                     if (S.st_a[N - 1] < sq) {
-                        int p2 = 0;
-                        while (S.st_a[p2] >= sq) ++p2;
+                        int p2 = N - 1;
+                        while (p2 > 0 && S.st_a[p2 - 1] < sq) --p2;
                         S.st_a[p2] = sq; S.st_id[p2] = S.g_id[q];
                     }
                 }
@@ -83,8 +83,10 @@ __device__ __forceinline__ void scan_push_t(ScanState &S, int N, float s, int32_
         S.st_a[p] = s; S.st_id[p] = item;
         S.thr = S.st_a[N - 1];
     } else {
-        int p = 0;
-        while (S.st_a[p] >= s) ++p;            // first slot strictly below s
+        // first slot strictly below s; a[] is sorted and a survivor usually beats only the tail,
+        // so the search walks up from the last slot (same slot as the reference's binary search)
+        int p = N - 1;
+        while (p > 0 && S.st_a[p - 1] < s) --p;
         S.st_a[p] = s; S.st_id[p] = item;      // overwrite, no shift (:142-144)
         S.thr = S.st_a[N - 1];
     }
@@ -104,12 +106,17 @@ __device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *
     atomicAdd(flags + 1, S.events);
 }
 
-__global__ void __launch_bounds__(256) k_row_norms(const float *X, int64_t rows, int k, float *out) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    float s = 0.0f;
-    for (int e = 0; e < k; ++e) s = __builtin_fmaf(X[r * k + e], X[r * k + e], s);
-    out[r] = __builtin_sqrtf(s);
+// max ||Q[i]||_2 over each tile of 32 consecutive items (one thread per tile)
+__global__ void __launch_bounds__(256) k_tile_norm_max(const float *Q, int64_t n, int k, float *out) {
+    const int64_t tl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tl * 32 >= n) return;
+    float best = 0.0f;
+    for (int64_t it = tl * 32; it < n && it < tl * 32 + 32; ++it) {
+        float s = 0.0f;
+        for (int e = 0; e < k; ++e) s = __builtin_fmaf(Q[it * k + e], Q[it * k + e], s);
+        best = fmaxf(best, s);
+    }
+    out[tl] = __builtin_sqrtf(best);
 }
 
 __global__ void __launch_bounds__(256) k_scores_one(const float *pu, const float *Q, int64_t n, int k, float *out) {
@@ -276,8 +283,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline size_t scan_bf16_lds_bytes(int k, int N) {
     const size_t tile = 2u * kScanTile * (k + 4) * sizeof(float);
     const size_t state = (size_t)kScanWaves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
-    const size_t sel = (size_t)kScanWaves * 32 * (2 * sizeof(float) + sizeof(uint32_t));   // thr, mu, masks
-    return tile + state + sel;
+    return tile + state;
 }
 
 template <int K16>
@@ -288,36 +294,33 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
     float *tile = reinterpret_cast<float *>(lds_raw);                       // [2][32][LD] fp32
     float *st_a_all = tile + 2 * kScanTile * LD;
     int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + kScanWaves * 32 * NS);
-    float *thr_all = reinterpret_cast<float *>(st_id_all + kScanWaves * 32 * NS);
-    float *mu_all = thr_all + kScanWaves * 32;
-    uint32_t *pm_all = reinterpret_cast<uint32_t *>(mu_all + kScanWaves * 32);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    float *thr_w = thr_all + w * 32, *mu_w = mu_all + w * 32;
-    uint32_t *pm_w = pm_all + w * 32;
 
     const int64_t upos = (int64_t)blockIdx.x * (kScanWaves * 32) + w * 32 + r;
     const bool uvalid = upos < a.nu;
     const int32_t uid = a.users[uvalid ? upos : 0];
     const float *prow = a.P + (int64_t)uid * K;
 
-    // exact fp32 row of user r (for the re-score chain) and its bf16 A fragments:
-    // lane (r,h) supplies A[row r][16*s + 8*h + j], j = 0..7, at step s
-    float pf[K];
+    // exact fp32 row of user r for the re-score chain, split over its two lanes: lane (r,h) keeps
+    // elements [h*K/2, (h+1)*K/2).  bf16 A fragments: lane (r,h) supplies A[row r][16*s + 8*h + j].
+    constexpr int KH = K / 2;
+    float mu;                                                  // margin factor of this lane's user
+    float pf[KH];
 #pragma unroll
-    for (int e = 0; e < K; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(prow + e); pf[e] = v[0]; pf[e + 1] = v[1]; pf[e + 2] = v[2]; pf[e + 3] = v[3]; }
+    for (int e = 0; e < KH; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(prow + h * KH + e); pf[e] = v[0]; pf[e + 1] = v[1]; pf[e + 2] = v[2]; pf[e + 3] = v[3]; }
     bf16x8 af[K16];
 #pragma unroll
     for (int s = 0; s < K16; ++s)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) af[s][jj] = (__bf16)prow[16 * s + 8 * h + jj];
-    if (h == 0) {
+    {
         float ss = 0.0f;
 #pragma unroll
-        for (int e = 0; e < K; ++e) ss = __builtin_fmaf(pf[e], pf[e], ss);
-        mu_w[r] = __builtin_sqrtf(ss) * (1.01f / 128.0f);      // 2^-7 ||P_u||, 1 % slack for the norm roundings
-        thr_w[r] = -INFINITY;
+        for (int e = 0; e < KH; ++e) ss = __builtin_fmaf(pf[e], pf[e], ss);
+        ss += __shfl_xor(ss, 32);
+        mu = __builtin_sqrtf(ss) * (1.01f / 128.0f);           // 2^-7 ||P_u||, 1 % slack for the norm roundings
     }
 
     // item tiles: global -> registers (one tile ahead) -> LDS, float4 granularity
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
             const int el = (tid + 256 * q) * 4;
             pre[q] = (el < kScanTile * K && el < limit) ? *reinterpret_cast<const f32x4 *>(src + el) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        nu_next = it0 + r < a.n ? a.item_norms[it0 + r] : 0.0f;
+        nu_next = a.tile_norm_max[it0 / kScanTile];             // largest ||Q_i|| of the tile (wave-uniform)
     };
     auto commit = [&](int buf) {
         float *dst = tile + buf * kScanTile * LD;
@@ -349,6 +352,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
     S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;
     S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
     int rescored = 0;
+    float thr_lane = -INFINITY;
     int64_t mcur = 0, mend = 0;
     int32_t mnext = 0x7fffffff;
     if (h == 0 && uvalid) {
@@ -369,32 +373,33 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         const float *tb = tile + cur * kScanTile * LD;
         if (t + 1 < ntiles) fetch(it0 + kScanTile);
 
-        // bf16 scores: lane (r,h) supplies B[16*s + 8*h + j][col r] from item r's fp32 row
+        // bf16 scores with ITEMS as rows and USERS as columns: lane (r,h) supplies A[item r][16*s+8*h+j]
+        // from item r's fp32 row in the tile and B[16*s+8*h+j][user r] from its user's fragments, and
+        // receives D[item (q&3)+8*(q>>2)+4*h][user r]: all 32 scores of user r sit on lanes r and r+32.
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-        const float *brow = tb + r * LD + 8 * h;
+        const float *irow = tb + r * LD + 8 * h;
 #pragma unroll
         for (int s = 0; s < K16; ++s) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(brow + 16 * s), b1 = *reinterpret_cast<const f32x4 *>(brow + 16 * s + 4);
-            bf16x8 bf;
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(irow + 16 * s), b1 = *reinterpret_cast<const f32x4 *>(irow + 16 * s + 4);
+            bf16x8 itf;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { bf[jj] = (__bf16)b0[jj]; bf[jj + 4] = (__bf16)b1[jj]; }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf, acc, 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj) { itf[jj] = (__bf16)b0[jj]; itf[jj + 4] = (__bf16)b1[jj]; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[s], acc, 0, 0, 0);
         }
 
-        // pre-filter: acc[q] is user row (q&3)+8*(q>>2)+4*h, item column r
-        const bool colok = it0 + r < a.n;
+        // pre-filter in registers: the user's threshold minus the margin is one per-lane value
+        const float bar = thr_lane - mu * nu;
+        uint32_t pmask = 0u;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            const bool pass = colok && (thr_w[row] < __builtin_fmaf(mu_w[row], nu, acc[q]));
-            const unsigned long long b = __ballot(pass);
-            if (r == 0) pm_w[row] = h ? (uint32_t)(b >> 32) : (uint32_t)b;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 16; ++q) pmask |= (bar < acc[q] ? 1u : 0u) << ((q & 3) + 8 * (q >> 2));
+        pmask <<= 4 * h;                                       // rows of lane (r,1) are shifted by 4
+        pmask |= (uint32_t)__shfl_xor((int)pmask, 32);         // both lanes of a user now hold all 32 columns
+        const int64_t left = a.n - it0;
+        if (left < kScanTile) pmask &= (1u << (uint32_t)left) - 1u;
 
+        uint32_t cand = 0u;
         if (h == 0 && uvalid) {
             uint32_t mb = 0u;
             while (mnext < it0 + kScanTile) {
@@ -402,25 +407,36 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
                 ++mcur;
                 mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
             }
-            uint32_t cand = pm_w[r] & ~mb;
-            while (cand) {
-                const int c = __ffs(cand) - 1;
-                cand &= cand - 1;
-                // exact score: k-ascending fp32 fma chain (== v_mfma_f32_32x32x2_f32, == oracle)
-                const float *qrow = tb + c * LD;
-                float s = 0.0f;
-#pragma unroll
-                for (int e = 0; e < K; e += 4) {
-                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
-                    s = __builtin_fmaf(pf[e], qv[0], s); s = __builtin_fmaf(pf[e + 1], qv[1], s);
-                    s = __builtin_fmaf(pf[e + 2], qv[2], s); s = __builtin_fmaf(pf[e + 3], qv[3], s);
-                }
-                ++rescored;
-                if (S.cnt == N && !(S.thr < s)) continue;
-                scan_push(S, N, s, (int32_t)(it0 + c), a.true_topn);
-            }
-            thr_w[r] = S.thr;
+            cand = pmask & ~mb;
         }
+        // Survivors, one per user and pass (wave-uniform loop).  Exact score = k-ascending fp32 fma
+        // chain (== v_mfma_f32_32x32x2_f32, == oracle): lane (r,0) runs elements [0,K/2) and hands the
+        // partial sum to lane (r,1), which runs [K/2,K) and hands the score back.
+        for (;;) {
+            int c = cand ? __ffs(cand) - 1 : -1;             // lanes h=1 have no list of their own
+            c = __shfl(c, r);                                 // both lanes of a user work on the same column
+            if (__ballot(c >= 0) == 0ull) break;
+            cand &= cand - 1;
+            float sc = 0.0f;
+            for (int ph = 0; ph < 2; ++ph) {
+                if (ph == 1) sc = __shfl(sc, r);              // partial of lane (r,0) -> lane (r,1)
+                if (h == ph && c >= 0) {
+                    const float *qrow = tb + c * LD + ph * KH;
+#pragma unroll
+                    for (int e = 0; e < KH; e += 4) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
+                        sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
+                        sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
+                    }
+                }
+            }
+            sc = __shfl(sc, r + 32);                          // finished score back to lane (r,0)
+            if (h == 0 && c >= 0) {
+                ++rescored;
+                if (!(S.cnt == N && !(S.thr < sc))) scan_push(S, N, sc, (int32_t)(it0 + c), a.true_topn);
+            }
+        }
+        thr_lane = __shfl(S.thr, r);                           // lane (r,1) filters with its user's threshold too
         if (t + 1 < ntiles) commit(cur ^ 1);
         nu = nu_next;
         __syncthreads();
