@@ -9,12 +9,16 @@ import random
 import numpy as np
 import pytest
 
-from test_host_golden import _c1_conf, _load
+from test_host_golden import ROOT, _c1_conf, _load
 from util import gj, gz, rel_err
 
 pytestmark = pytest.mark.gpu
 
 SEED = 20260002
+
+
+def conf_path(tmp_path, k, iters):
+    return str(tmp_path / ('c1_%d_%d.conf' % (k, iters)))
 
 
 def _trained(tmp_path, capsys, iters=1, topn='5,10'):
@@ -96,3 +100,25 @@ def test_round_semantics_track_the_sequential_loop_on_model_quality(tmp_path, ca
     assert all(b < a for a, b in zip(rnd[0], rnd[0][1:]))                 # monotone, as the sequential curve
     assert abs(rnd[0][-1] - seq[0][-1]) < 0.01 * seq[0][-1]               # final loss within 1 %
     assert abs(rnd[1] - seq[1]) < 0.005                                    # Precision@10 within noise
+
+
+def test_cross_validation_forks_before_touching_hip(tmp_path):
+    """yue.py -cv: folds run in forked processes (reference yue.py:87-105).  HIP cannot be used in a
+    child forked from a parent that initialised it, so the parent must stay HIP-free: the device
+    context is created inside each fold on first use.  Runs in a fresh interpreter for that reason."""
+    import subprocess
+    import sys
+    conf = _c1_conf(tmp_path, 10, 2, '5,10')
+    text = open(conf_path(tmp_path, 10, 2)).read().replace('evaluation.setup=-target track -byTime 0.2', 'evaluation.setup=-target track -cv 2')
+    text = text.replace('-mode replay', '-mode epoch -round 1024 -seed 2')
+    cv_conf = tmp_path / 'cv.conf'
+    cv_conf.write_text(text)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from yue_amd.tool.config import Config\nfrom yue_amd.yue import Yue\n"
+            "Yue(Config(%r)).execute()\n") % (ROOT, str(cv_conf))
+    res = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = res.stdout.decode()
+    assert res.returncode == 0, out[-2000:]
+    assert 'BPR [1] iteration 2' in out and 'BPR [2] iteration 2' in out
+    assert 'The result of 2-fold cross validation:' in out and 'Precision:' in out.split('2-fold cross validation:')[1]
+    assert glob.glob(str(tmp_path / 'results' / '*2-fold-cv.txt'))
