@@ -122,3 +122,43 @@ def test_cross_validation_forks_before_touching_hip(tmp_path):
     assert 'BPR [1] iteration 2' in out and 'BPR [2] iteration 2' in out
     assert 'The result of 2-fold cross validation:' in out and 'Precision:' in out.split('2-fold cross validation:')[1]
     assert glob.glob(str(tmp_path / 'results' / '*2-fold-cv.txt'))
+
+
+def test_array_native_data_through_the_plugin_surface(tmp_path, capsys):
+    """a BASELINE-config-2-like problem (k=64) as integer arrays through
+    BPR(conf, ArrayRecord).execute(): initModel -> buildModel (epoch mode) -> evalRanking."""
+    from yue_amd import synth
+    from yue_amd.data.arrays import ArrayRecord
+    from yue_amd.evaluation.measure import Measure
+    from yue_amd.recommender.cf.BPR import BPR
+    from yue_amd._shim import Device
+    m, n, d, k = 20000, 8000, 30, 64
+    data = synth.make_arrays(m, n, d, seed=9)
+    tp, ti = synth.make_test_arrays(m, n, d, 6, data['indptr'], data['indices'], seed=9)
+    rec_data = ArrayRecord(m, n, data['ev_ptr'], data['ev_i'], tp, ti)
+    assert np.array_equal(rec_data.indptr, data['indptr']) and np.array_equal(rec_data.indices, data['indices'])
+    conf = _c1_conf(tmp_path, k, 3, '10,20')
+    conf.config['bpr.hip'] = '-mode epoch -round 16384 -seed 4 -gpu 0'
+    rec = BPR(conf, rec_data)
+    np.random.seed(5)
+    measure = rec.execute()
+    out = capsys.readouterr().out
+    assert 'BPR [1] iteration 3' in out and measure[0] == 'Top 10\n' and measure[6] == 'Top 20\n'
+    losses = [float(ln.split('loss = ')[1].split(',')[0]) for ln in out.splitlines() if 'iteration' in ln]
+    assert losses[2] < losses[1] < losses[0]
+    # the lists are what the library gives for the trained factors ...
+    dev = Device(0, raise_errors=True)
+    dev.set_factors(rec.P, rec.Q)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    ids, _ = dev.topn_scan(rec.recUsers, 20)
+    dev.close()
+    assert np.array_equal(ids, rec.recIds) and len(rec.recUsers) == len(rec_data.testSet) > 0.9 * m
+    # ... and the vectorised measures agree with the name-based Measure on the same lists
+    users = [str(u) for u in rec.recUsers[:3000]]
+    origin = {u: rec_data.testSet[u] for u in users}
+    res = {u: [str(x) for x in rec.recIds[t]] for t, u in enumerate(users)}
+    from yue_amd.data.arrays import ranking_measure_ids
+    want = Measure.rankingMeasure(origin, res, [10, 20], n)
+    got = ranking_measure_ids(tp, ti, rec.recUsers[:3000], rec.recIds[:3000], [10, 20], n)
+    for a, b in zip(want, got):
+        assert a == b or abs(float(a.split(':')[1]) - float(b.split(':')[1])) < 1e-12

@@ -12,6 +12,7 @@ from math import isnan
 
 import numpy as np
 
+from ..data.arrays import ArrayRecord, ranking_measure_ids
 from ..evaluation.measure import Measure
 from ..tool import config
 from .recommender import Recommender
@@ -120,6 +121,8 @@ class IterativeRecommender(Recommender):
         if N > 100 or N < 0:
             print('N can not be larger than 100! It has been reassigned with 10')
             N = 10
+        if isinstance(self.data, ArrayRecord):
+            return self._evalRanking_arrays(top, N)
         res = ['userId: recommendations in (itemId, ranking score) pairs, * means the item matches.\n']
         users = list(self.data.testSet.keys())
         ids = self._scan(users, N) if users else np.zeros((0, N), np.int32)
@@ -133,6 +136,25 @@ class IterativeRecommender(Recommender):
             wanted = self.data.testSet[user]
             res.append(user + ':' + ''.join(item + '*' if item in wanted else item for item in recList[user]) + '\n')
         self._write_results(res, recList, top)
+
+    def _evalRanking_arrays(self, top, N):
+        """Array-native data: lists stay integer (``self.recUsers``, ``self.recIds``), the measures are
+        computed on ids (data/arrays.py: ranking_measure_ids), only the measure file is written -- a
+        lists file of concatenated numeric names would be unreadable."""
+        from os.path import abspath
+        from time import localtime, strftime, time
+        from ..tool.file import FileIO
+        d = self.data
+        uids = d.testSet.user_ids().astype(np.int32)
+        if not getattr(self, '_device_factors_current', False):
+            self._sync_factors_to_device()
+        self.recUsers = uids
+        self.recIds = self.dev.topn_scan(uids, N)[0] if len(uids) else np.zeros((0, N), np.int32)
+        self.measure = ranking_measure_ids(d.test_indptr, d.test_indices, uids, self.recIds, top, d.getSize(self.recType))
+        stamp = strftime("%Y-%m-%d %H-%M-%S", localtime(time()))
+        FileIO.writeFile(self.output['-dir'], self.config['recommender'] + '@' + stamp + '-measure' + self.foldInfo + '.txt', self.measure)
+        print('The result has been output to ', abspath(self.output['-dir']), '.')
+        print('The result of %s %s:\n%s' % (self.algorName, self.foldInfo, ''.join(self.measure)))
 
     def ranking_performance(self):
         N = 10

@@ -17,6 +17,7 @@ from collections import defaultdict
 from os.path import abspath
 from time import localtime, strftime, time
 
+from ..data.arrays import ArrayRecord
 from ..data.record import Record
 from ..evaluation.measure import Measure
 from ..tool.config import LineConfig
@@ -31,7 +32,8 @@ class Recommender(object):
         self.foldInfo = fold
         self.isSaveModel = self.isLoadModel = False
         self.isOutput = True
-        self.data = Record(conf, trainingSet, testSet)
+        # an ArrayRecord (integer arrays) is taken as it is; text-log events go through Record
+        self.data = trainingSet if isinstance(trainingSet, ArrayRecord) else Record(conf, trainingSet, testSet)
         self.evalConfig = LineConfig(conf['evaluation.setup'])
         self.recType = self.evalConfig['-target'] if self.evalConfig.contains('-target') else 'track'
         if self.evalConfig.contains('-cold'):

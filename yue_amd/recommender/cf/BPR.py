@@ -21,6 +21,7 @@ from random import choice
 import numpy as np
 
 from ...base.IterativeRecommender import IterativeRecommender
+from ...data.arrays import ArrayRecord
 from ...tool.config import LineConfig
 
 
@@ -59,11 +60,15 @@ class BPR(IterativeRecommender):
 
     def buildModel(self):
         opts = self._options()
+        if isinstance(self.data, ArrayRecord) and opts['-mode'] == 'replay':
+            print('array-native data needs bpr.hip=-mode epoch (the replay mode samples over item names)')
+            exit(-1)
         self._sync_factors_to_device()
         dev, arr = self.dev, self._arrays
-        ev_u = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(arr['ev_ptr']))
-        listened_names = {user: {ev[self.recType] for ev in events} for user, events in self.data.userRecord.items()}
-        itemList = list(self.data.name2id[self.recType].keys())
+        if opts['-mode'] == 'replay':
+            ev_u = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(arr['ev_ptr']))
+            listened_names = {user: {ev[self.recType] for ev in events} for user, events in self.data.userRecord.items()}
+            itemList = list(self.data.name2id[self.recType].keys())
         print('training...')
         iteration = 0
         while iteration < self.maxIter:

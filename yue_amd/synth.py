@@ -93,3 +93,24 @@ def init_factors(m, n, k, seed=20260002):
     P = rs.rand(m, k).astype(np.float32) / 10
     Q = rs.rand(n, k).astype(np.float32) / 10
     return P, Q
+
+
+def make_test_arrays(m, n, d, d_test, indptr, indices, seed=20260001, user_chunk=1 << 18):
+    """Held-out items per user for the array-native path: slots d .. d+d_test-1 of the same stream,
+    de-duplicated and with the user's training items removed.  Returns (test_indptr, test_indices)."""
+    rows, counts = [], np.empty(m, dtype=np.int64)
+    slots = np.arange(d, d + d_test, dtype=np.uint64)[None, :]
+    for u0 in range(0, m, user_chunk):
+        u1 = min(m, u0 + user_chunk)
+        users = np.arange(u0, u1, dtype=np.uint64)[:, None]
+        it = np.sort(event_items(seed, users, slots, n), axis=1)
+        keep = np.ones(it.shape, dtype=bool)
+        keep[:, 1:] = it[:, 1:] != it[:, :-1]
+        ukey = np.repeat(np.arange(u0, u1, dtype=np.int64), d_test).reshape(it.shape) * n + it
+        train_keys = np.repeat(np.arange(u0, u1, dtype=np.int64), np.diff(indptr[u0:u1 + 1])) * n + indices[indptr[u0]:indptr[u1]]
+        keep &= ~np.isin(ukey, train_keys)
+        counts[u0:u1] = keep.sum(axis=1)
+        rows.append(it[keep])
+    tp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(counts, out=tp[1:])
+    return tp, np.concatenate(rows).astype(np.int32)
