@@ -162,3 +162,18 @@ def test_array_native_data_through_the_plugin_surface(tmp_path, capsys):
     got = ranking_measure_ids(tp, ti, rec.recUsers[:3000], rec.recIds[:3000], [10, 20], n)
     for a, b in zip(want, got):
         assert a == b or abs(float(a.split(':')[1]) - float(b.split(':')[1])) < 1e-12
+
+
+def test_save_and_load_model_round_trip(tmp_path, capsys):
+    # the reference leaves saveModel / loadModel empty (base/IterativeRecommender.py:41-45); here they
+    # store P and Q (.npz) and the load branch of execute() (base/recommender.py:157-159) ranks from them
+    from yue_amd.recommender.cf.BPR import BPR
+    rec, _ = _trained(tmp_path, capsys, 1)
+    rec.evalRanking()
+    first = list(rec.measure)
+    rec.saveModel()
+    conf = _c1_conf(tmp_path, 10, 1, '5,10')
+    again = BPR(conf, _load(conf), [])
+    again.isLoadModel = True
+    assert again.execute() == first
+    assert np.array_equal(again.P, rec.P) and np.array_equal(again.Q, rec.Q)

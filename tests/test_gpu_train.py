@@ -244,3 +244,47 @@ def test_full_size_properties(dev):
     P2, Q2 = d2.get_factors()
     d2.close()
     assert rel_err(P2, P) < TOL and rel_err(Q2, Q) < TOL
+
+
+@pytest.mark.parametrize('m,n,k', [(1, 3, 1), (2, 2, 3), (5, 40, 16), (3, 70, 256)])
+def test_degenerate_shapes(orc, m, n, k):
+    # smallest and widest supported shapes through every entry point
+    from yue_amd._shim import Device
+    rs = np.random.RandomState(m * 100 + n + k)
+    P0 = rs.rand(m, k).astype(np.float32) / 10
+    Q0 = rs.rand(n, k).astype(np.float32) / 10
+    per_user = [np.sort(rs.choice(n, size=rs.randint(1, n), replace=False)) for _ in range(m)]
+    ev = [rs.permutation(np.repeat(r, 2))[:max(1, len(r))] for r in per_user]
+    ev_ptr = np.cumsum([0] + [len(e) for e in ev]).astype(np.int64)
+    ev_i = np.concatenate(ev).astype(np.int32)
+    indptr = np.cumsum([0] + [len(r) for r in per_user]).astype(np.int64)
+    indices = np.concatenate(per_user).astype(np.int32)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(ev_ptr))
+    dev = Device(0, raise_errors=True)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(indptr, indices, ev_ptr, ev_i)
+    j = dev.sample_negatives(9, 0)
+    assert np.array_equal(j, orc.sample_counter(9, 0, ev_u, n, indptr, indices))
+    nll, sp, sq = dev.bpr_epoch(9, 0, 3, 0.05, 0.01, 0.02)
+    Po, Qo = P0.copy(), Q0.copy()
+    E = len(ev_u)
+    rp = np.unique(np.concatenate([np.arange(0, E, 3), [E]])).astype(np.int64)
+    nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.05, 0.01, 0.02)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
+    dev.set_factors(P0, Q0)
+    ok = j >= 0
+    nll = dev.bpr_replay(ev_u[ok], ev_i[ok], j[ok], 0.05, 0.01, 0.02)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_sequential(Po, Qo, ev_u[ok], ev_i[ok], j[ok], 0.05, 0.01, 0.02)
+    P, Q = dev.get_factors()
+    assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
+    if k <= 128:
+        mp = np.zeros(m + 1, np.int64)
+        users = np.arange(m, dtype=np.int32)
+        N = min(n, 3)
+        ids, sc = dev.topn_scan(users, N, mp, np.zeros(0, np.int32))
+        oid, osc, rc = orc.topn_scan(P, Q, users, N, mp, np.zeros(0, np.int32))
+        assert rc == 0 and np.array_equal(ids, oid) and np.array_equal(sc, osc)
+        assert np.array_equal(dev.scores(0), orc.scores(P, Q, 0))
+    dev.close()
