@@ -114,6 +114,30 @@ def bench_scoring(args, cp):
         kms += ms
     cp.barrier()
     dt = cp.reduce_max(time.perf_counter() - t0)
+    cpu = None
+    if cp.rank == 0 and cp.world == 1 and not args.no_cpu_baseline:
+        # oracle/ (restates base/IterativeRecommender.py:96-145) on one core, bounded sample of the same users
+        import oracle
+        orc = oracle.Oracle()
+        P, Q = dev.get_factors()
+
+        def rows_of(sel):
+            rws = [data['indices'][data['indptr'][x]:data['indptr'][x + 1]] for x in sel]
+            mp = np.zeros(len(sel) + 1, np.int64)
+            mp[1:] = np.cumsum([len(x) for x in rws])
+            return mp, np.concatenate(rws)
+        t1 = time.perf_counter()
+        orc.topn_scan(P, Q, users[:4], N, *rows_of(users[:4]))
+        per_user = (time.perf_counter() - t1) / 4
+        S = int(max(4, min(len(users), 12.0 / per_user)))
+        t1 = time.perf_counter()
+        oid, _, _ = orc.topn_scan(P, Q, users[:S], N, *rows_of(users[:S]))
+        cdt = time.perf_counter() - t1
+        if not np.array_equal(oid, ids[:S]):
+            sys.exit('scoring bench: lists differ from the oracle')
+        cpu = {'value': S / cdt, 'unit': 'users/s', 'cores': 1, 'kind': 'port',
+               'sample': 'first %d users of the same workload (all %d items each), oracle/bpr_oracle.c:orc_topn_scan, %.1f s on %s; lists equal the GPU lists'
+                         % (S, n, cdt, _cpu_name())}
     if cp.rank == 0:
         flop = 2.0 * len(users) * n * k
         ach = flop * args.steps / (kms * 1e-3)
@@ -126,7 +150,8 @@ def bench_scoring(args, cp):
                                    % (args.workload.upper(), m, n, k, N), 'state_machine_events_per_user': events / max(1, len(users)),
                        'exact_rescores_per_user': rescored / max(1, len(users)), 'bf16_prefilter': used_bf16},
             'roofline': {'bound': 'mfma', 'kernel': ('k_topn_scan_bf16<K16=%d>' % (k // 16)) if used_bf16 else ('k_topn_scan<K2=%d>' % (k // 2)), 'achieved': ach / 1e12, 'peak': peak / 1e12,
-                         'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel_ms_per_scan': kms / args.steps, 'traffic': None}}))
+                         'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel_ms_per_scan': kms / args.steps, 'traffic': None},
+            'cpu_baseline': cpu}))
     dev.close()
     cp.close()
 
