@@ -177,3 +177,22 @@ def test_save_and_load_model_round_trip(tmp_path, capsys):
     again.isLoadModel = True
     assert again.execute() == first
     assert np.array_equal(again.P, rec.P) and np.array_equal(again.Q, rec.Q)
+
+
+def test_nan_loss_aborts_like_the_reference(tmp_path, capsys):
+    # base/IterativeRecommender.py:63-66: a NaN loss prints the message and exits with -1; the NaN has to
+    # come back from the device for that (error convention)
+    from yue_amd.recommender.cf.BPR import BPR
+    for mode in ('replay', 'epoch -round 4096'):
+        conf = _c1_conf(tmp_path, 10, 2, '5,10')
+        conf.config['bpr.hip'] = '-mode %s -gpu 0' % mode
+        rec = BPR(conf, _load(conf), [])
+        rec.readConfiguration()
+        random.seed(SEED)
+        np.random.seed(SEED)
+        rec.initModel()
+        rec.P[3, 2] = np.nan
+        with pytest.raises(SystemExit) as stop:
+            rec.buildModel()
+        assert stop.value.code == -1
+        assert 'Loss = NaN or Infinity' in capsys.readouterr().out
