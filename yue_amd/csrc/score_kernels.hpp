@@ -409,32 +409,38 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
             }
             cand = pmask & ~mb;
         }
-        // Survivors, one per user and pass (wave-uniform loop).  Exact score = k-ascending fp32 fma
-        // chain (== v_mfma_f32_32x32x2_f32, == oracle): lane (r,0) runs elements [0,K/2) and hands the
-        // partial sum to lane (r,1), which runs [K/2,K) and hands the score back.
+        // Survivors.  Exact score = k-ascending fp32 fma chain (== v_mfma_f32_32x32x2_f32, == oracle),
+        // run as a two-stage pipeline over the user's two lanes: in every phase lane (r,0) takes the
+        // user's next survivor through elements [0,K/2) while lane (r,1) finishes the previous one
+        // through [K/2,K) from the partial handed over -- one chain execution per phase for the whole
+        // wave, survivors complete in ascending item order.
+        int c_prev = -1;
+        float s_prev = 0.0f;
         for (;;) {
-            int c = cand ? __ffs(cand) - 1 : -1;             // lanes h=1 have no list of their own
-            c = __shfl(c, r);                                 // both lanes of a user work on the same column
-            if (__ballot(c >= 0) == 0ull) break;
-            cand &= cand - 1;
-            float sc = 0.0f;
-            for (int ph = 0; ph < 2; ++ph) {
-                if (ph == 1) sc = __shfl(sc, r);              // partial of lane (r,0) -> lane (r,1)
-                if (h == ph && c >= 0) {
-                    const float *qrow = tb + c * LD + ph * KH;
+            const int c_pop = (h == 0 && cand) ? __ffs(cand) - 1 : -1;
+            const int c_from = __shfl(c_prev, r);
+            const float s_from = __shfl(s_prev, r);
+            const int c_cur = h ? c_from : c_pop;
+            float sc = h ? s_from : 0.0f;
+            if (__ballot(c_cur >= 0) == 0ull) break;
+            if (c_pop >= 0) cand &= cand - 1;
+            if (c_cur >= 0) {
+                const float *qrow = tb + c_cur * LD + h * KH;
 #pragma unroll
-                    for (int e = 0; e < KH; e += 4) {
-                        const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
-                        sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
-                        sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
-                    }
+                for (int e = 0; e < KH; e += 4) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
+                    sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
+                    sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
                 }
             }
-            sc = __shfl(sc, r + 32);                          // finished score back to lane (r,0)
-            if (h == 0 && c >= 0) {
+            const float s_done = __shfl(sc, r + 32);          // finished scores travel back to lane (r,0)
+            const int c_done = __shfl(c_cur, r + 32);
+            if (h == 0 && c_done >= 0) {
                 ++rescored;
-                if (!(S.cnt == N && !(S.thr < sc))) scan_push(S, N, sc, (int32_t)(it0 + c), a.true_topn);
+                if (!(S.cnt == N && !(S.thr < s_done))) scan_push(S, N, s_done, (int32_t)(it0 + c_done), a.true_topn);
             }
+            c_prev = c_cur;
+            s_prev = sc;
         }
         thr_lane = __shfl(S.thr, r);                           // lane (r,1) filters with its user's threshold too
         if (t + 1 < ntiles) commit(cur ^ 1);
