@@ -203,8 +203,13 @@ constexpr unsigned kOobOffset = 0x80000000u;
 constexpr unsigned long long kTouch = 0x100000001ull;      // +1 touch in both halves of a counter word
 constexpr int kRsrcFlags = 0x00020000;
 
+// evu / evi / evj: the event arrays again, as restrict-qualified read-only views of THIS round's
+// range, so that the wave-uniform reads of a batch's (u, i, j) become scalar loads (s_load): they do
+// not queue behind the vector-memory traffic of the other waves.  (The prep role writes ev_j of the
+// NEXT round's range through a.ev_j -- a disjoint range.)
 template <int KR, int TPW>
-__global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
+__global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const int32_t *__restrict__ evu,
+                                               const int32_t *__restrict__ evi, const int32_t *__restrict__ evj) {
     const int lane = threadIdx.x & 63;
     if ((int)blockIdx.x < ra.prep_blocks) {
         const int64_t e = ra.n_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -225,14 +230,20 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
     const int64_t base = ra.e_begin + wave * TPW;
     if (base >= ra.e_end) return;
 
-    int u = 0, i = 0, j = -1;
-    uint32_t ci = 0, cj = 0;             // touches of my rows in this round (the immutable half)
-    if (lane < TPW && base + lane < ra.e_end) {
-        u = a.ev_u[base + lane];
-        i = a.ev_i[base + lane];
-        j = a.ev_j[base + lane];
-        if (j >= 0) { ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32); }
+    // batch header through the scalar unit: (u, i, j) of the TPW events
+    int hu[TPW], hi_[TPW], hj[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const bool ex = base + t < ra.e_end;
+        const int64_t ix = ex ? base + t : ra.e_end - 1;
+        hu[t] = evu[ix]; hi_[t] = evi[ix]; hj[t] = ex ? evj[ix] : -1;
     }
+    // lane t keeps event t (the retire phase and the loss work per lane)
+    int i = 0, j = -1;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) if (lane == t) { i = hi_[t]; j = hj[t]; }
+    uint32_t ci = 0, cj = 0;             // touches of my rows in this round (the immutable half)
+    if (lane < TPW && j >= 0) { ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32); }
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = k * 4u;
     unsigned vo[KR];
@@ -243,10 +254,7 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
     // batch's smallest user id, so the 31-bit byte offsets hold for any number of users
     unsigned u0 = 0xffffffffu;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const unsigned ut = (unsigned)__builtin_amdgcn_readlane(u, t);
-        if (base + t < ra.e_end && ut < u0) u0 = ut;
-    }
+    for (int t = 0; t < TPW; ++t) if (base + t < ra.e_end && (unsigned)hu[t] < u0) u0 = (unsigned)hu[t];
     const uint64_t qbytes = (uint64_t)a.n * row_bytes, pbytes = (uint64_t)(a.m - u0) * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
     const int prec = (int)(pbytes < 0x7fffffffull ? pbytes : 0x7fffffffull);
@@ -260,9 +268,9 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra) {
     float qi[TPW][KR], qj[TPW][KR], p[TPW][KR];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        ru_[t] = (unsigned)__builtin_amdgcn_readlane(u, t);
-        ri_[t] = (unsigned)__builtin_amdgcn_readlane(i, t);
-        const int tj = __builtin_amdgcn_readlane(j, t);
+        ru_[t] = (unsigned)hu[t];
+        ri_[t] = (unsigned)hi_[t];
+        const int tj = hj[t];
         ok[t] = tj >= 0;                                 // no event / sampler gave up: nothing is written
         rj_[t] = ok[t] ? (unsigned)tj : 0u;
         oi[t] = ri_[t] * row_bytes; oj[t] = rj_[t] * row_bytes;

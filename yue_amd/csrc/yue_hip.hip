@@ -155,13 +155,13 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
     }
     const dim3 grid((unsigned)blocks), block(256);
     switch (kr_of(c->k) * 16 + tpw) {
-        case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra); break;
-        case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round<2, 8>), grid, block, 0, c->stream, a, ra); break;
-        case 4 * 16 + 4: hipLaunchKernelGGL((yue::k_round<4, 4>), grid, block, 0, c->stream, a, ra); break;
-        case 1 * 16 + 4: hipLaunchKernelGGL((yue::k_round<1, 4>), grid, block, 0, c->stream, a, ra); break;
-        case 2 * 16 + 4: hipLaunchKernelGGL((yue::k_round<2, 4>), grid, block, 0, c->stream, a, ra); break;
-        case 1 * 16 + 2: hipLaunchKernelGGL((yue::k_round<1, 2>), grid, block, 0, c->stream, a, ra); break;
-        case 2 * 16 + 2: hipLaunchKernelGGL((yue::k_round<2, 2>), grid, block, 0, c->stream, a, ra); break;
+        case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
+        case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round<2, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
+        case 4 * 16 + 4: hipLaunchKernelGGL((yue::k_round<4, 4>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
+        case 1 * 16 + 4: hipLaunchKernelGGL((yue::k_round<1, 4>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
+        case 2 * 16 + 4: hipLaunchKernelGGL((yue::k_round<2, 4>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
+        case 1 * 16 + 2: hipLaunchKernelGGL((yue::k_round<1, 2>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
+        case 2 * 16 + 2: hipLaunchKernelGGL((yue::k_round<2, 2>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
     }
     if (timed) {
