@@ -194,11 +194,8 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 // the vector ALU.  A lane whose element index is >= k gets a voffset beyond num_records: the
 // hardware returns 0 for its loads and drops its stores and atomics.
 #define YUE_BLOAD(rs, vo, so) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rs), (vo), (so), 0))
-#define YUE_BSTORE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), YUE_STORE_AUX)
+#define YUE_BSTORE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 0)
 #define YUE_BATOMIC(val, rs, vo, so) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((val), (rs), (vo), (so), 0)
-#ifndef YUE_STORE_AUX
-#define YUE_STORE_AUX 0      // cache policy bits of the in-place row stores (16 = sc1, write-through)
-#endif
 constexpr unsigned kOobOffset = 0x80000000u;
 constexpr unsigned long long kTouch = 0x100000001ull;      // +1 touch in both halves of a counter word
 constexpr int kRsrcFlags = 0x00020000;
