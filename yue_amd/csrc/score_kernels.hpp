@@ -106,17 +106,18 @@ __device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *
     atomicAdd(flags + 1, S.events);
 }
 
-// max ||Q[i]||_2 over each tile of 32 consecutive items (one thread per tile)
+// max ||Q[i]||_2 over each tile of 32 consecutive items: one wave per tile, lane pair (r, h) sums half
+// of item r's squares
 __global__ void __launch_bounds__(256) k_tile_norm_max(const float *Q, int64_t n, int k, float *out) {
-    const int64_t tl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t tl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tl * 32 >= n) return;
-    float best = 0.0f;
-    for (int64_t it = tl * 32; it < n && it < tl * 32 + 32; ++it) {
-        float s = 0.0f;
-        for (int e = 0; e < k; ++e) s = __builtin_fmaf(Q[it * k + e], Q[it * k + e], s);
-        best = fmaxf(best, s);
-    }
-    out[tl] = __builtin_sqrtf(best);
+    const int64_t it = tl * 32 + r;
+    float s = 0.0f;
+    if (it < n) for (int e = h; e < k; e += 2) s = __builtin_fmaf(Q[it * k + e], Q[it * k + e], s);
+    s += __shfl_xor(s, 32);
+    for (int off = 16; off >= 1; off >>= 1) s = fmaxf(s, __shfl_xor(s, off));
+    if (lane == 0) out[tl] = __builtin_sqrtf(s) * 1.0001f;      // the two half sums round differently: keep it an upper bound
 }
 
 __global__ void __launch_bounds__(256) k_scores_one(const float *pu, const float *Q, int64_t n, int k, float *out) {

@@ -609,7 +609,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
     const int64_t ntile = (c->n + 31) / 32;
     HIPCHK(c->s_norms.resize(ntile));
-    hipLaunchKernelGGL(yue::k_tile_norm_max, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
+    hipLaunchKernelGGL(yue::k_tile_norm_max, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
     sa.tile_norm_max = c->s_norms.p;
     hipEvent_t t0, t1;
     HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
