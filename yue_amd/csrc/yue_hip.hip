@@ -261,8 +261,9 @@ int yue_ctx_destroy(yue_ctx *c) {
     if (!c) return YUE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
-    if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->ev_rounds) (void)hipEventDestroy(c->ev_rounds);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
