@@ -115,9 +115,12 @@ int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_time
  * done behind the bf16 pre-filter, and whether the bf16 pre-filter kernel ran (k in 16/32/64/128). */
 int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t *rescored, int *used_bf16);
 
-/* Tuning / diagnostic knobs (results do not depend on the first two):
+/* Tuning / diagnostic knobs (list results do not depend on the first two; round_stage changes only the order of fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
  *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8
+ *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in
+ *               staging rows (write-through stores, summed in event order by the last toucher);
+ *               0: every contended row goes through float atomics
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
  *               the reference's order-dependent overwrite-scan */

@@ -20,6 +20,11 @@ constexpr int kMaxAttempts = 64;
 
 struct TrainArgs {
     float *P, *Q, *dP, *dQ;
+    float *stage;                // staged item-row differences of the running round: one k-float row per touch
+#ifdef YUE_STAMPS
+    unsigned long long *stamps;  // diagnostic build only (make stamps): 8 phase time stamps per update wave, then per prep block
+    long long stamp_waves;
+#endif
     const int32_t *ev_u, *ev_i;
     int32_t *ev_j;
     const int64_t *indptr;
@@ -45,6 +50,10 @@ struct RoundArgs {
     unsigned long long *cnt_next;    // round [n_begin, n_end)
     uint32_t *cntp_cur;          // user-row flushes (runs of equal users inside a wave's batch) in this round
     uint32_t *cntp_next;         // ... in the next round
+    // Slot table, kStageMax words per item row: the staging slots (2*(event - first event of the round)
+    // + 0 for the positive / 1 for the negative) of the row's first kStageMax touches, in ticket order.
+    uint32_t *tab_cur, *tab_next;
+    int staged;                  // 1: rows with 2..kStageMax touches go through the staging rows instead of float atomics
     int apply_p;                 // 1: user rows are finished in this launch; 0: dP is left for the all-reduce
     int sample_next;             // 1: draw ev_j for the next round (fused sampler); 0: ev_j is given
     int prep_blocks;             // blocks [0, prep_blocks) run the sample+count role
@@ -184,8 +193,14 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 // pass (lane t holds triplet t), then writes:
 //   * an item row touched exactly once in the round (cnt == 1): the new row, in place, plain
 //     stores -- nobody else reads or writes it this round;
-//   * a contended row: (new - old) added into dQ with float atomics; the last toucher of the row
-//     (touch count reaching zero) adds dQ to the row once and leaves dQ zeroed.
+//   * a row with 2..kStageMax touches: (new - old) written to the touch's own staging row with
+//     write-through (sc1) stores; the last toucher of the row (touch count reaching zero: every other
+//     toucher has drained its stores before its decrement) reads the staged rows back with sc1 loads,
+//     adds them in event order -- the order of the oracle's sum -- and rewrites the row once.
+//     Scattered 512-byte float-atomic rows run at ~2.4e9/s on MI355X, stores and loads at ~1.1e10/s
+//     (tools/experiments/rowops.hip), and most contended rows of a round have 2-3 touches;
+//   * a hotter row: (new - old) added into dQ with float atomics; the last toucher swaps the sum out
+//     of dQ (leaving it zeroed) and rewrites the row.
 // P[u] differences are summed in registers over a run of equal users and flushed into dP; user
 // rows are finished by the same last-arriver rule (or, on a communicator, by the all-reduce).
 // ------------------------------------------------------------------------------------------
@@ -195,10 +210,18 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 // hardware returns 0 for its loads and drops its stores and atomics.
 #define YUE_BLOAD(rs, vo, so) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rs), (vo), (so), 0))
 #define YUE_BSTORE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 0)
+#define YUE_BLOAD_SC1(rs, vo, so) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rs), (vo), (so), 16))
+#define YUE_BSTORE_SC1(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 16)
 #define YUE_BATOMIC(val, rs, vo, so) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((val), (rs), (vo), (so), 0)
+#ifdef YUE_STAMPS
+#define YUE_STAMP(ix, waits) do { asm volatile(waits ::: "memory"); if (a.stamps && lane == 0) a.stamps[(size_t)wave * 8 + (ix)] = wall_clock64(); } while (0)
+#else
+#define YUE_STAMP(ix, waits) do {} while (0)
+#endif
 constexpr unsigned kOobOffset = 0x80000000u;
 constexpr unsigned long long kTouch = 0x100000001ull;      // +1 touch in both halves of a counter word
 constexpr int kRsrcFlags = 0x00020000;
+constexpr unsigned kStageMax = 4;                          // touches per row served by the staging rows
 
 // evu / evi / evj: the event arrays again, as restrict-qualified read-only views of THIS round's
 // range, so that the wave-uniform reads of a batch's (u, i, j) become scalar loads (s_load): they do
@@ -209,23 +232,39 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
                                                const int32_t *__restrict__ evi, const int32_t *__restrict__ evj) {
     const int lane = threadIdx.x & 63;
     if ((int)blockIdx.x < ra.prep_blocks) {
+#ifdef YUE_STAMPS
+        if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8] = wall_clock64();
+#endif
         const int64_t e = ra.n_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (e < ra.n_end) {
             const int32_t i = a.ev_i[e];
             int32_t j;
             if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
             else j = a.ev_j[e];
-            if (j >= 0) { atomicAdd(ra.cnt_next + i, kTouch); atomicAdd(ra.cnt_next + j, kTouch); }
+            if (j >= 0) {
+                // the low half before the add is this touch's ticket on its row
+                const uint32_t ti = (uint32_t)atomicAdd(ra.cnt_next + i, kTouch), tj = (uint32_t)atomicAdd(ra.cnt_next + j, kTouch);
+                if (ra.staged) {
+                    const uint32_t slot = 2u * (uint32_t)(e - ra.n_begin);
+                    if (ti < kStageMax) ra.tab_next[(size_t)i * kStageMax + ti] = slot;
+                    if (tj < kStageMax) ra.tab_next[(size_t)j * kStageMax + tj] = slot + 1u;
+                }
+            }
             if (ra.apply_p) {      // one flush per run of equal users inside a TPW-aligned batch
                 const int32_t u = a.ev_u[e];
                 if ((e - ra.n_begin) % TPW == 0 || a.ev_u[e - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
             }
         }
+#ifdef YUE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8 + 7] = wall_clock64();
+#endif
         return;
     }
     const int64_t wave = (int64_t)(blockIdx.x - ra.prep_blocks) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t base = ra.e_begin + wave * TPW;
     if (base >= ra.e_end) return;
+    YUE_STAMP(0, "");
 
     // batch header through the scalar unit: (u, i, j) of the TPW events
     int hu[TPW], hi_[TPW], hj[TPW];
@@ -239,8 +278,20 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     int i = 0, j = -1;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) if (lane == t) { i = hi_[t]; j = hj[t]; }
+    YUE_STAMP(1, "s_waitcnt lgkmcnt(0)");
     uint32_t ci = 0, cj = 0;             // touches of my rows in this round (the immutable half)
-    if (lane < TPW && j >= 0) { ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32); }
+    uint32_t si[kStageMax], sj[kStageMax];       // staging slots of my rows' touches (sorted below)
+#pragma unroll
+    for (unsigned q = 0; q < kStageMax; ++q) si[q] = sj[q] = 0xffffffffu;
+    if (lane < TPW && j >= 0) {
+        ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32);
+        if (ra.staged) {
+            const uint4 wi = *reinterpret_cast<const uint4 *>(ra.tab_cur + (size_t)i * kStageMax);
+            const uint4 wj = *reinterpret_cast<const uint4 *>(ra.tab_cur + (size_t)j * kStageMax);
+            si[0] = wi.x; si[1] = wi.y; si[2] = wi.z; si[3] = wi.w;
+            sj[0] = wj.x; sj[1] = wj.y; sj[2] = wj.z; sj[3] = wj.w;
+        }
+    }
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = k * 4u;
     unsigned vo[KR];
@@ -259,6 +310,8 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     const auto rsdQ = __builtin_amdgcn_make_buffer_rsrc(a.dQ, 0, qrec, kRsrcFlags);
     const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.P + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
     const auto rsdP = __builtin_amdgcn_make_buffer_rsrc(a.dP + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
+    // staging rows of this round: 2 per event (the host keeps 2 * events * row_bytes below 2^31 when staged)
+    const auto rsS = __builtin_amdgcn_make_buffer_rsrc(a.stage, 0, ra.staged ? (int)(2u * (unsigned)(ra.e_end - ra.e_begin) * row_bytes) : 0, kRsrcFlags);
 
     unsigned oi[TPW], oj[TPW], ou[TPW], ru_[TPW], ri_[TPW], rj_[TPW];
     bool ok[TPW];
@@ -280,6 +333,7 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
 #pragma unroll
         for (int r = 0; r < KR; ++r) p[t][r] = YUE_BLOAD(rsP, vo[r], ou[t]);
 
+    YUE_STAMP(2, "s_waitcnt vmcnt(0)");
     float xs = 0.0f;                                     // lane t will hold the margin of triplet t
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -298,6 +352,17 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     double nll = (lane < TPW && j >= 0) ? -log(s) : 0.0;           // BPR.py:58
     __builtin_amdgcn_sched_barrier(0);
 
+    YUE_STAMP(3, "");
+    // entries beyond the row's touch count are leftovers of earlier rounds: drop them, then put the
+    // slots in ascending order = event order, the order in which the oracle sums a row's differences
+    static_assert(kStageMax == 4, "the sorting network below is written for four slots");
+#pragma unroll
+    for (unsigned q = 0; q < kStageMax; ++q) { if (q >= ci) si[q] = 0xffffffffu; if (q >= cj) sj[q] = 0xffffffffu; }
+#define YUE_CSWAP(x, y) { const uint32_t lo_ = min(x, y), hi2_ = max(x, y); x = lo_; y = hi2_; }
+    YUE_CSWAP(si[0], si[1]) YUE_CSWAP(si[2], si[3]) YUE_CSWAP(si[0], si[2]) YUE_CSWAP(si[1], si[3]) YUE_CSWAP(si[1], si[2])
+    YUE_CSWAP(sj[0], sj[1]) YUE_CSWAP(sj[2], sj[3]) YUE_CSWAP(sj[0], sj[2]) YUE_CSWAP(sj[1], sj[3]) YUE_CSWAP(sj[1], sj[2])
+#undef YUE_CSWAP
+
     float dp[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
@@ -307,15 +372,21 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float c = rdlane(cs, t);
-        const bool uniq_i = __builtin_amdgcn_readlane(ci, t) == 1u;
-        const bool uniq_j = __builtin_amdgcn_readlane(cj, t) == 1u;
+        const unsigned cti = (unsigned)__builtin_amdgcn_readlane(ci, t), ctj = (unsigned)__builtin_amdgcn_readlane(cj, t);
+        const bool uniq_i = cti == 1u, uniq_j = ctj == 1u;
+        const bool stg_i = ra.staged && cti <= kStageMax, stg_j = ra.staged && ctj <= kStageMax;
+        const unsigned ss = 2u * ((unsigned)wave * TPW + t) * row_bytes;     // my two staging rows
         if (ok[t]) {                                     // wave-uniform
             run_ok = true;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 const Elem o = bpr_elem(p[t][r], qi[t][r], qj[t][r], c, a.ru, a.ri);
-                if (uniq_i) YUE_BSTORE(o.qi2, rsQ, vo[r], oi[t]); else YUE_BATOMIC(o.qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
-                if (uniq_j) YUE_BSTORE(o.qj2, rsQ, vo[r], oj[t]); else YUE_BATOMIC(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
+                if (uniq_i) YUE_BSTORE(o.qi2, rsQ, vo[r], oi[t]);
+                else if (stg_i) YUE_BSTORE_SC1(o.qi2 - qi[t][r], rsS, vo[r], ss);
+                else YUE_BATOMIC(o.qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
+                if (uniq_j) YUE_BSTORE(o.qj2, rsQ, vo[r], oj[t]);
+                else if (stg_j) YUE_BSTORE_SC1(o.qj2 - qj[t][r], rsS, vo[r], ss + row_bytes);
+                else YUE_BATOMIC(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
                 dp[r] += o.p2 - p[t][r];
             }
             if (lane == 0) {                             // sole toucher: reset the counter here
@@ -344,7 +415,9 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     // its own adds are acknowledged; whoever takes the count to zero knows every add of the round
     // has been performed and every toucher has read the row: it swaps the sum out of dQ (returning
     // atomic: coherent at the memory side, leaves dQ zeroed) and rewrites the row.
+    YUE_STAMP(4, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    YUE_STAMP(5, "");
     bool last_i = false, last_j = false, last_p = false;
     if (lane < TPW && j >= 0) {
         if (ci != 1u) last_i = (uint32_t)atomicAdd(ra.cnt_cur + i, ~0ull) == 1u;     // -1 on the low half
@@ -354,10 +427,12 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     // winners: bits [0,TPW) = item row i of that lane, [TPW,2*TPW) = row j, [2*TPW,3*TPW) = user run
     unsigned long long win = (__ballot(last_i) & ((1ull << TPW) - 1)) | ((__ballot(last_j) & ((1ull << TPW) - 1)) << TPW) |
                              ((__ballot(last_p) & ((1ull << TPW) - 1)) << (2 * TPW));
+    YUE_STAMP(6, "s_waitcnt vmcnt(0)");
     while (win) {
         // up to four rows per pass: all swaps and row loads are issued before the first store
         float *xp[4], *dx[4];
         bool act[4];
+        unsigned nst[4], so[4][kStageMax];               // staged rows to add (0: the row went through dQ / dP)
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
             act[sl] = win != 0;
@@ -367,6 +442,12 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
             const unsigned row = b < TPW ? (unsigned)__builtin_amdgcn_readlane(i, src)
                                  : b < 2 * TPW ? (unsigned)__builtin_amdgcn_readlane(j, src)
                                                : (unsigned)__builtin_amdgcn_readlane((int)run_u, src);
+            const unsigned touches = b < TPW ? (unsigned)__builtin_amdgcn_readlane(ci, src)
+                                     : b < 2 * TPW ? (unsigned)__builtin_amdgcn_readlane(cj, src) : 0u;
+            nst[sl] = act[sl] && ra.staged && b < 2 * TPW && touches <= kStageMax ? touches : 0u;
+#pragma unroll
+            for (unsigned q = 0; q < kStageMax; ++q)
+                so[sl][q] = (b < TPW ? (unsigned)__builtin_amdgcn_readlane(si[q], src) : (unsigned)__builtin_amdgcn_readlane(sj[q], src)) * row_bytes;
             const uint64_t o = (uint64_t)row * k;
             xp[sl] = (b < 2 * TPW ? a.Q : a.P) + o;
             dx[sl] = (b < 2 * TPW ? a.dQ : a.dP) + o;
@@ -376,10 +457,30 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl)
             if (act[sl]) {
+                if (nst[sl]) {
+                    // every load of the staged bytes is an sc1 load issued after this wave's own
+                    // decrement returned; slots beyond the count get an out-of-range offset (reads 0)
+                    float st[kStageMax][KR];
 #pragma unroll
-                for (int r = 0; r < KR; ++r) {
-                    const unsigned e = 64u * r + lane;
-                    if (e < k) { d[sl][r] = atomicExch(dx[sl] + e, 0.0f); x[sl][r] = xp[sl][e]; }
+                    for (unsigned q = 0; q < kStageMax; ++q)
+#pragma unroll
+                        for (int r = 0; r < KR; ++r)
+                            st[q][r] = YUE_BLOAD_SC1(rsS, q < nst[sl] ? vo[r] : kOobOffset, q < nst[sl] ? so[sl][q] : 0u);
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        const unsigned e = 64u * r + lane;
+                        if (e < k) x[sl][r] = xp[sl][e];
+                        float acc = st[0][r];
+#pragma unroll
+                        for (unsigned q = 1; q < kStageMax; ++q) acc = acc + st[q][r];
+                        d[sl][r] = acc;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        const unsigned e = 64u * r + lane;
+                        if (e < k) { d[sl][r] = atomicExch(dx[sl] + e, 0.0f); x[sl][r] = xp[sl][e]; }
+                    }
                 }
             }
 #pragma unroll
@@ -392,6 +493,7 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
                 }
             }
     }
+    YUE_STAMP(7, "s_waitcnt vmcnt(0)");
 #pragma unroll
     for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
     if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);

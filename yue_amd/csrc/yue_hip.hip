@@ -63,6 +63,13 @@ struct yue_ctx {
     DevBuf<float> P, Q, dP, dQ;
     DevBuf<unsigned long long> cnt0, cnt1;       // item-row touch counters of the even / odd round (total | remaining)
     DevBuf<uint32_t> cntp0, cntp1;               // user-row flushes of the even / odd round
+    DevBuf<uint32_t> tab0, tab1;                 // staging-slot tables of the even / odd round (kStageMax words per item row)
+    DevBuf<float> stage;                         // staged item-row differences: 2 rows per event of the largest round
+    bool staged = false;                         // the running call uses the staging rows
+#ifdef YUE_STAMPS
+    DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
+    int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0, stamp_prep = 0;
+#endif
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> xu, xi, xj;          // explicit triplets (replay / rounds)
@@ -79,6 +86,7 @@ struct yue_ctx {
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
+    int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
     // kernel timing
     int timing_stride = 0;
     int64_t launch_counter = 0;
@@ -99,6 +107,7 @@ int kr_of(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : 4; }   // registers per l
 yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
     yue::TrainArgs a{};
     a.P = c->P.p; a.Q = c->Q.p; a.dP = c->dP.p; a.dQ = c->dQ.p;
+    a.stage = c->stage.p;
     a.ev_u = c->ev_u.p; a.ev_i = c->ev_i.p; a.ev_j = c->ev_j.p;
     a.indptr = c->indptr.p; a.indices = c->indices.p;
     a.nll_slots = c->scal.p;
@@ -129,13 +138,15 @@ int tpw_of(const yue_ctx *c) {
 
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
 // Every timing_stride-th launch is bracketed with HIP events on the library's stream.
-int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
+int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
                  int parity, int sample_next, int apply_p) {
     unsigned long long *cnt[2] = {c->cnt0.p, c->cnt1.p};
     uint32_t *cntp[2] = {c->cntp0.p, c->cntp1.p};
     yue::RoundArgs ra{};
     ra.e_begin = e0; ra.e_end = e1; ra.n_begin = n0; ra.n_end = n1;
     ra.cnt_cur = cnt[parity]; ra.cnt_next = cnt[parity ^ 1]; ra.cntp_cur = cntp[parity]; ra.cntp_next = cntp[parity ^ 1];
+    uint32_t *tab[2] = {c->tab0.p, c->tab1.p};
+    ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1]; ra.staged = c->staged ? 1 : 0;
     ra.sample_next = sample_next; ra.apply_p = apply_p;
     ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
     const int tpw = tpw_of(c);
@@ -154,6 +165,20 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
         HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].first, c->stream));
     }
     const dim3 grid((unsigned)blocks), block(256);
+#ifdef YUE_STAMPS
+    yue::TrainArgs a = a_in;
+    a.stamps = nullptr;
+    if (e1 > e0 && c->update_launches++ == c->stamp_launch) {
+        HIPCHK(c->stamps.resize((size_t)(waves + ra.prep_blocks) * 8));
+        HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)(waves + ra.prep_blocks) * 64, c->stream));
+        a.stamps = c->stamps.p;
+        a.stamp_waves = waves;
+        c->stamp_waves = waves;
+        c->stamp_prep = ra.prep_blocks;
+    }
+#else
+    const yue::TrainArgs &a = a_in;
+#endif
     switch (kr_of(c->k) * 16 + tpw) {
         case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round<2, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
@@ -175,8 +200,18 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, in
 // Runs the non-empty rounds bounds[r]..bounds[r+1] in order.  after_round(r) is called once the
 // launches of round r are queued (the communicator path hooks its all-reduce there).
 template <typename F>
-int run_rounds(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int64_t> &bounds, int sample, int apply_p, F after_round) {
+int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int sample, int apply_p, F after_round) {
     const int64_t R = (int64_t)bounds.size() - 1;
+    // staging rows: two per event of the largest round, addressed with 31-bit byte offsets
+    int64_t widest = 0;
+    for (int64_t r = 0; r < R; ++r) widest = std::max(widest, bounds[(size_t)r + 1] - bounds[(size_t)r]);
+    c->staged = c->opt_round_stage && widest > 0 && 2 * widest * (int64_t)c->k * 4 < (1ll << 31);
+    if (c->staged) {
+        HIPCHK(c->stage.resize((size_t)(2 * widest) * (size_t)c->k));
+        HIPCHK(c->tab0.resize((size_t)c->n * yue::kStageMax));
+        HIPCHK(c->tab1.resize((size_t)c->n * yue::kStageMax));
+        a.stage = c->stage.p;
+    }
     std::vector<int64_t> ne;                                // indices of non-empty rounds
     for (int64_t r = 0; r < R; ++r) if (bounds[(size_t)r + 1] > bounds[(size_t)r]) ne.push_back(r);
     int rc;
@@ -269,6 +304,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
+    c->tab0.release(); c->tab1.release(); c->stage.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
@@ -553,6 +589,10 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     const std::string key(name);
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
+    if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
+#ifdef YUE_STAMPS
+    if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
+#endif
     if (key == "round_tpw") {
         if (value != 0 && value != 2 && value != 4 && value != 8) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw must be 0, 2, 4 or 8");
         if (value == 8 && kr_of(c->k) == 4) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw 8 needs k <= 128");
@@ -561,6 +601,18 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     }
     return fail(YUE_ERR_ARG, "yue_set_option: unknown option " + key);
 }
+
+#ifdef YUE_STAMPS
+// Diagnostic build only (make stamps; not part of include/yue_hip.h): the 8 wall_clock64 stamps
+// (100 MHz) of every update wave of the launch chosen with yue_set_option("debug_stamp_launch", i).
+int yue_debug_get_stamps(yue_ctx *c, unsigned long long *out, int64_t max_waves, int64_t *n_waves) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int64_t w = std::min(max_waves, c->stamp_waves + c->stamp_prep);
+    if (w > 0) HIPCHK(hipMemcpy(out, c->stamps.p, (size_t)w * 64, hipMemcpyDeviceToHost));
+    *n_waves = c->stamp_waves;          // the rows after these are the prep blocks' (start, .., end)
+    return YUE_OK;
+}
+#endif
 
 int yue_scores(yue_ctx *c, int32_t user, float *out_n) {
     if (!c || !c->have_factors || !out_n) return fail(YUE_ERR_ARG, "yue_scores: no factors uploaded");
