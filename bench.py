@@ -166,6 +166,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--scan-f32', action='store_true', help='scoring workloads: force the exact f32-MFMA kernel')
     ap.add_argument('--tpw', type=int, default=0, help='tuning: events per wave in the round kernel (0 = default)')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE', help='tuning: yue_set_option(NAME, VALUE), repeatable')
     ap.add_argument('--force-comm', action='store_true', help='N=1 only: run the communicator code path with a 1-rank RCCL communicator')
     args = ap.parse_args()
 
@@ -192,6 +193,9 @@ def main():
     attach_device(dev, cp)
     if args.tpw:
         dev.set_option('round_tpw', args.tpw)
+    for kv in args.opt:
+        name, value = kv.split('=')
+        dev.set_option(name, int(value))
     if args.force_comm and world == 1:
         from yue_amd._shim import comm_unique_id
         dev.comm_init(comm_unique_id(), 0, 1)

@@ -64,11 +64,13 @@ struct yue_ctx {
     DevBuf<unsigned long long> cnt0, cnt1;       // item-row touch counters of the even / odd round (total | remaining)
     DevBuf<uint32_t> cntp0, cntp1;               // user-row flushes of the even / odd round
     DevBuf<uint32_t> tab0, tab1;                 // staging-slot tables of the even / odd round (kStageMax words per item row)
-    DevBuf<float> stage;                         // staged item-row differences: 2 rows per event of the largest round
+    // staged item rows (2 per event of the widest round) live behind the n item rows in the Q allocation,
+    // so that "new row in place" and "new row to my staging row" are the same store with another offset
     bool staged = false;                         // the running call uses the staging rows
 #ifdef YUE_STAMPS
     DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
     int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0, stamp_prep = 0;
+    int dbg_flags = 0;
 #endif
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
@@ -87,6 +89,8 @@ struct yue_ctx {
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
+    int opt_epoch_sampler = 0;           // 0: negatives of an epoch drawn by one pass up front; 1: by the round launches (fused)
+    int opt_round_layout = 0;            // 0: quarter-wave round kernel where k % 4 == 0; 1: always the full-wave kernel
     // kernel timing
     int timing_stride = 0;
     int64_t launch_counter = 0;
@@ -107,7 +111,7 @@ int kr_of(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : 4; }   // registers per l
 yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
     yue::TrainArgs a{};
     a.P = c->P.p; a.Q = c->Q.p; a.dP = c->dP.p; a.dQ = c->dQ.p;
-    a.stage = c->stage.p;
+    a.stage = c->Q.p ? c->Q.p + (size_t)c->n * c->k : nullptr;
     a.ev_u = c->ev_u.p; a.ev_i = c->ev_i.p; a.ev_j = c->ev_j.p;
     a.indptr = c->indptr.p; a.indices = c->indices.p;
     a.nll_slots = c->scal.p;
@@ -136,6 +140,12 @@ int tpw_of(const yue_ctx *c) {
     return kr_of(c->k) == 4 ? 4 : 8;      // measured on C3 (k=128): 8 events per wave 53.9 ms/epoch, 4 -> 58.7 ms
 }
 
+// k % 4 == 0: the quarter-wave round kernel (4 events per wave, 16 per workgroup) unless the caller asked for
+// the full-wave one (option round_layout 1, or an explicit round_tpw other than 4)
+bool quarter_layout(const yue_ctx *c) {
+    return c->opt_round_layout == 0 && c->k % 4 == 0 && (c->opt_round_tpw == 0 || c->opt_round_tpw == 4);
+}
+
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
 // Every timing_stride-th launch is bracketed with HIP events on the library's stream.
 int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
@@ -149,7 +159,8 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1]; ra.staged = c->staged ? 1 : 0;
     ra.sample_next = sample_next; ra.apply_p = apply_p;
     ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
-    const int tpw = tpw_of(c);
+    const bool quarter = quarter_layout(c);
+    const int tpw = quarter ? 4 : tpw_of(c);
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
     const int64_t blocks = ra.prep_blocks + (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
@@ -168,6 +179,7 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 #ifdef YUE_STAMPS
     yue::TrainArgs a = a_in;
     a.stamps = nullptr;
+    a.dbg = c->dbg_flags;
     if (e1 > e0 && c->update_launches++ == c->stamp_launch) {
         HIPCHK(c->stamps.resize((size_t)(waves + ra.prep_blocks) * 8));
         HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)(waves + ra.prep_blocks) * 64, c->stream));
@@ -179,6 +191,13 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 #else
     const yue::TrainArgs &a = a_in;
 #endif
+    if (quarter) {
+        switch (kr_of(c->k)) {
+            case 1: hipLaunchKernelGGL((yue::k_round_q<1>), grid, block, 0, c->stream, a, ra); break;
+            case 2: hipLaunchKernelGGL((yue::k_round_q<2>), grid, block, 0, c->stream, a, ra); break;
+            default: hipLaunchKernelGGL((yue::k_round_q<4>), grid, block, 0, c->stream, a, ra); break;
+        }
+    } else
     switch (kr_of(c->k) * 16 + tpw) {
         case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round<2, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
@@ -205,12 +224,21 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
     // staging rows: two per event of the largest round, addressed with 31-bit byte offsets
     int64_t widest = 0;
     for (int64_t r = 0; r < R; ++r) widest = std::max(widest, bounds[(size_t)r + 1] - bounds[(size_t)r]);
-    c->staged = c->opt_round_stage && widest > 0 && 2 * widest * (int64_t)c->k * 4 < (1ll << 31);
+    c->staged = c->opt_round_stage && widest > 0 && (c->n + 2 * widest) * (int64_t)c->k * 4 < (1ll << 31);
     if (c->staged) {
-        HIPCHK(c->stage.resize((size_t)(2 * widest) * (size_t)c->k));
+        const size_t need = (size_t)(c->n + 2 * widest) * (size_t)c->k;
+        if (c->Q.n < need) {                                // grow the item allocation, keep the rows
+            DevBuf<float> bigger;
+            HIPCHK(bigger.resize(need));
+            HIPCHK(hipMemcpyAsync(bigger.p, c->Q.p, (size_t)c->n * c->k * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->Q.release();
+            c->Q = bigger;
+            a.Q = c->Q.p;
+        }
         HIPCHK(c->tab0.resize((size_t)c->n * yue::kStageMax));
         HIPCHK(c->tab1.resize((size_t)c->n * yue::kStageMax));
-        a.stage = c->stage.p;
+        a.stage = c->Q.p + (size_t)c->n * c->k;
     }
     std::vector<int64_t> ne;                                // indices of non-empty rounds
     for (int64_t r = 0; r < R; ++r) if (bounds[(size_t)r + 1] > bounds[(size_t)r]) ne.push_back(r);
@@ -304,7 +332,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
-    c->tab0.release(); c->tab1.release(); c->stage.release();
+    c->tab0.release(); c->tab1.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
@@ -449,7 +477,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     for (int64_t r = 0; r < n_rounds; ++r) if (round_ptr[r + 1] < round_ptr[r]) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr must be non-decreasing");
     if (c->m * (int64_t)c->k * 4 >= (1ll << 31)) {
         // the round kernel addresses P relative to the smallest user of a wave's batch with 31-bit offsets
-        const int tpw = tpw_of(c);
+        const int tpw = quarter_layout(c) ? yue::kBlockEvents : tpw_of(c);
         for (int64_t r = 0; r < n_rounds; ++r)
             for (int64_t b = round_ptr[r]; b < round_ptr[r + 1]; b += tpw) {
                 int32_t lo = u[b], hi = u[b];
@@ -506,11 +534,15 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     int rc = zero_scalars(c);
     if (rc) return rc;
     const int64_t E = c->E;
+    // negatives of the whole epoch in one pass (same counter-based draws as the per-round fused sampler,
+    // which shares the chip with the update waves of the previous round and costs more there)
+    const int fused_sampler = c->opt_epoch_sampler == 1;
+    if (!fused_sampler && E > 0) hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, a, E);
     std::vector<int64_t> bounds;
     if (!c->comm) {
         for (int64_t e0 = 0; e0 < E; e0 += round_events) bounds.push_back(e0);
         bounds.push_back(E);
-        if ((rc = run_rounds(c, a, bounds, 1, 1, [](int64_t) { return YUE_OK; }))) return rc;
+        if ((rc = run_rounds(c, a, bounds, fused_sampler, 1, [](int64_t) { return YUE_OK; }))) return rc;
     } else {
         // Same user blocks on every rank: the block width comes from the job-wide event count.
         double etot = (double)E;
@@ -538,7 +570,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
                                c->P.p, c->dP.p, first, count);
             return YUE_OK;
         };
-        if ((rc = run_rounds(c, a, bounds, 1, 0, after))) return rc;
+        if ((rc = run_rounds(c, a, bounds, fused_sampler, 0, after))) return rc;
         // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
@@ -590,7 +622,14 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
+    if (key == "epoch_sampler") { c->opt_epoch_sampler = value != 0; return YUE_OK; }
+    if (key == "round_layout") {
+        if (value != 0 && value != 1) return fail(YUE_ERR_ARG, "yue_set_option: round_layout must be 0 (quarter-wave where k % 4 == 0) or 1 (full-wave)");
+        c->opt_round_layout = (int)value;
+        return YUE_OK;
+    }
 #ifdef YUE_STAMPS
+    if (key == "debug_flags") { c->dbg_flags = (int)value; return YUE_OK; }
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
 #endif
     if (key == "round_tpw") {
