@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: BPR triplet-updates/s at k=128 (BASELINE.json metric) on N MI355X.
 
-A "step" is one epoch: one pass of the fused sampler + BPR update path over the whole synthetic
+A "step" is one epoch: one pass of the counter-based sampler + BPR update path over the whole synthetic
 event list (BASELINE config 3: 1M users x 200K items, 50 events/user = 50M triplets), factors and
 interactions resident in HBM before the timed region starts.  For N > 1 the driver launches one
 process per GPU (torch.distributed.run); every rank owns an item shard of the same shape (weak
@@ -238,11 +238,11 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: BPR k=%d, %d users x %d items per GPU, %d events/user (%d triplets per epoch per GPU), '
-                                   'fused counter-based sampler, S-round W=%d events, lr=%g regU=regI=%g'
+                                   'counter-based sampler (one pass per epoch, inside the timed step), S-round W=%d events, lr=%g regU=regI=%g'
                                    % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),
                        'round_events': args.round_events, 'parallelism': 'items sharded x%d, users replicated' % world,
                        'setup_s': round(setup_s, 1), 'final_nll_per_triplet': nll / E},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + next-round sampler blocks)' % (1 if k <= 64 else 2 if k <= 128 else 4),
+            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + next-round touch-count blocks)' % (1 if k <= 64 else 2 if k <= 128 else 4),
                          'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                          'algorithmic_bytes_per_triplet': ab, 'launches_timed': k_launches,
                          'avg_launch_ms': (k_ms / k_launches) if k_launches else None,

@@ -77,7 +77,7 @@ int yue_bpr_rounds(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32
                    double lr, double regU, double regI, double *nll_out);
 
 /*
- * One epoch over the uploaded events with the fused counter-based negative sampler.
+ * One epoch over the uploaded events; negatives from the device's counter-based sampler.
  * Rounds are round_events consecutive events (on a communicator: user-aligned blocks of about
  * that many events, identical user ranges on every rank, user-factor gradients all-reduced).
  * Outputs: nll (sum of -log s over this rank's triplets), sums of squares of P and of this
@@ -87,7 +87,7 @@ int yue_bpr_epoch(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int64_t round_eve
                   double lr, double regU, double regI,
                   double *nll_out, double *sumsqP_out, double *sumsqQ_out);
 
-/* Negatives the fused sampler draws for (seed, epoch): j_out[E], -1 where all attempts were rejected. */
+/* Negatives the device sampler draws for (seed, epoch): j_out[E], -1 where all attempts were rejected. */
 int yue_sample_negatives(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int32_t *j_out);
 
 int yue_sumsq(yue_ctx *ctx, double *sumsqP_out, double *sumsqQ_out);
@@ -115,9 +115,11 @@ int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_time
  * done behind the bf16 pre-filter, and whether the bf16 pre-filter kernel ran (k in 16/32/64/128). */
 int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t *rescored, int *used_bf16);
 
-/* Tuning / diagnostic knobs (list results do not depend on the first two; round_stage changes only the order of fp32 sums):
+/* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
  *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8
+ *   "epoch_sampler" 0 (default): yue_bpr_epoch draws the epoch's negatives in one pass up front;
+ *               1: the round launches draw the next round's negatives themselves (same negatives)
  *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in
  *               staging rows (write-through stores, summed in event order by the last toucher);
  *               0: every contended row goes through float atomics

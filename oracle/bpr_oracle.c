@@ -185,52 +185,12 @@ static float dot64(const float *a, const float *b, int k) {
     return part[0];
 }
 
-/*
- * The S-round kernels for k % 4 == 0 lay a row out over 16 lanes (lane h holds floats
- * [4h + 64v, 4h + 64v + 4), v < KV; KV = 1, 2, 4 for k <= 64, 128, 256): each lane adds its
- * products in element order, then a butterfly with partner h^1, h^2, h^4, h^8
- * (yue_amd/csrc/train_kernels.hpp, k_round_q).  Same products, another association.
- */
-static float dot16(const float *a, const float *b, int k) {
-    const int kv = k <= 64 ? 1 : k <= 128 ? 2 : 4;
-    float part[16];
-    for (int h = 0; h < 16; h++) {
-        float acc = 0.0f;
-        for (int v = 0; v < kv; v++)
-            for (int c = 0; c < 4; c++) {
-                int e = 4 * h + 64 * v + c;
-                float pr = e < k ? a[e] * b[e] : 0.0f;
-                acc = acc + pr;
-            }
-        part[h] = acc;
-    }
-    for (int off = 1; off <= 8; off <<= 1) {
-        float nxt[16];
-        for (int h = 0; h < 16; h++) nxt[h] = part[h] + part[h ^ off];
-        memcpy(part, nxt, sizeof part);
-    }
-    return part[0];
-}
-
-/* which dot order the round functions restate: 0 = the library's default (dot16 where k % 4 == 0,
- * else dot64), 1 = always dot64 (yue_set_option "round_layout" 1, or fewer than 4 events per wave) */
-static int g_round_layout = 0;
-void orc_set_round_layout(int layout) { g_round_layout = layout; }
-
 typedef struct { float c, ru, ri; double s; } coef_t;
 
 /* BPR.py:50 + qmath.py:115-116: s in double on the fp32 margin; coefficient rounded to fp32 once */
-static coef_t coef_x(float x, double lr, double regU, double regI);
 static coef_t coef(const float *p, const float *qi, const float *qj, int k, double lr, double regU, double regI) {
-    return coef_x(dot64(p, qi, k) - dot64(p, qj, k), lr, regU, regI);
-}
-/* the same for a triplet of an S-round */
-static coef_t coef_round(const float *p, const float *qi, const float *qj, int k, double lr, double regU, double regI) {
-    if (g_round_layout == 0 && k % 4 == 0) return coef_x(dot16(p, qi, k) - dot16(p, qj, k), lr, regU, regI);
-    return coef(p, qi, qj, k, lr, regU, regI);
-}
-static coef_t coef_x(float x, double lr, double regU, double regI) {
     coef_t r;
+    float x = dot64(p, qi, k) - dot64(p, qj, k);
     r.s = 1.0 / (1.0 + exp(-(double)x));
     r.c = (float)(lr * (1.0 - r.s));
     r.ru = (float)(lr * regU);
@@ -285,7 +245,7 @@ double orc_bpr_rounds(float *P, float *Q, int64_t m, int64_t n, int k,
         for (int64_t t = round_ptr[r]; t < round_ptr[r + 1]; t++) {
             if (j[t] < 0) continue;
             const float *p = P + (int64_t)u[t] * k, *qi = Q + (int64_t)i[t] * k, *qj = Q + (int64_t)j[t] * k;
-            coef_t cf = coef_round(p, qi, qj, k, lr, regU, regI);
+            coef_t cf = coef(p, qi, qj, k, lr, regU, regI);
             float *dp = dP + (int64_t)u[t] * k, *dqi = dQ + (int64_t)i[t] * k, *dqj = dQ + (int64_t)j[t] * k;
             for (int e = 0; e < k; e++) {
                 float p2, qi2, qj2;
@@ -320,7 +280,7 @@ double orc_bpr_round_deltas(const float *P, const float *Q, int k,
     for (int64_t t = 0; t < T; t++) {
         if (j[t] < 0) continue;
         const float *p = P + (int64_t)u[t] * k, *qi = Q + (int64_t)i[t] * k, *qj = Q + (int64_t)j[t] * k;
-        coef_t cf = coef_round(p, qi, qj, k, lr, regU, regI);
+        coef_t cf = coef(p, qi, qj, k, lr, regU, regI);
         float *dp = dP + (int64_t)u[t] * k, *dqi = dQ + (int64_t)i[t] * k, *dqj = dQ + (int64_t)j[t] * k;
         for (int e = 0; e < k; e++) {
             float p2, qi2, qj2;

@@ -59,11 +59,6 @@ class Oracle(object):
         return j
 
     # -- training ---------------------------------------------------------------
-    def set_round_layout(self, layout):
-        """Dot order restated by the round functions: 0 = the library's default kernels (16-lane order
-        where k % 4 == 0), 1 = the 64-lane order everywhere (yue_set_option 'round_layout' 1, or 2 events per wave)."""
-        self.lib.orc_set_round_layout(C.c_int(layout))
-
     def bpr_sequential(self, P, Q, u, i, j, lr, regU, regI):
         """In place on P, Q (float32 C-contiguous). Returns sum(-log s)."""
         assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous

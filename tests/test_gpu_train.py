@@ -152,7 +152,7 @@ def test_fused_epoch_matches_oracle(dev, orc, m, n, d, k, W):
     E = len(ev_u)
     rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
     for epoch in range(2):
-        # integer work: the fused sampler's negatives are bit-exact with the oracle's
+        # integer work: the device sampler's negatives are bit-exact with the oracle's
         j_gpu = dev.sample_negatives(seed, epoch)
         j_orc = orc.sample_counter(seed, epoch, ev_u, n, data['indptr'], data['indices'])
         assert np.array_equal(j_gpu, j_orc)
@@ -164,36 +164,53 @@ def test_fused_epoch_matches_oracle(dev, orc, m, n, d, k, W):
         assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
 
 
-@pytest.mark.parametrize('tpw,layout', [(2, 1), (4, 0), (8, 0), (8, 1), (4, 1)])
-def test_round_kernel_under_heavy_contention_and_many_wave_passes(orc, tpw, layout):
+@pytest.mark.parametrize('tpw', [2, 4, 8])
+def test_round_kernel_under_heavy_contention_and_many_wave_passes(orc, tpw):
     # few items, big rounds: every item row is contended (about 40 touches per row and round, hot rows
     # several hundred), and the grid has more waves than the chip holds at once (late waves must still
     # see the round's touch totals, not the retired counts).  The fp32 order of the atomic sums is the
-    # only freedom left; measured 1e-6 .. 6e-6 here, against the 1e-5 bar.  Both round kernels: layout 0 =
-    # quarter-wave (16-lane dot order), layout 1 = full-wave (64-lane order; the only one with 2 events per wave).
+    # only freedom left; measured 1e-6 .. 6e-6 here, against the 1e-5 bar.
     from yue_amd._shim import Device
     m, n, d, k, W = 30000, 3000, 20, 64, 65536
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=77)
     dev = Device(0, raise_errors=True)
     dev.set_option('round_tpw', tpw)
-    dev.set_option('round_layout', layout)
     dev.set_factors(P0, Q0)
     dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
     Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
     rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
-    orc.set_round_layout(layout)
-    try:
-        for epoch in range(2):
-            j = orc.sample_counter(5, epoch, ev_u, n, data['indptr'], data['indices'])
-            nll, _, _ = dev.bpr_epoch(5, epoch, W, 0.01, 0.01, 0.01)
-            nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.01, 0.01, 0.01)
-            P, Q = dev.get_factors()
-            assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
-            assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
-    finally:
-        orc.set_round_layout(0)
+    for epoch in range(2):
+        j = orc.sample_counter(5, epoch, ev_u, n, data['indptr'], data['indices'])
+        nll, _, _ = dev.bpr_epoch(5, epoch, W, 0.01, 0.01, 0.01)
+        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.01, 0.01, 0.01)
+        P, Q = dev.get_factors()
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
+        assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    dev.close()
+
+
+def test_tuning_knobs_do_not_change_the_epoch(orc):
+    # epoch_sampler: the same negatives either way -> identical factors up to the order of atomic sums;
+    # round_stage: staging rows vs float atomics for rows with 2..4 touches -> same sums, another fp32 order
+    from yue_amd._shim import Device
+    m, n, d, k, W = 4000, 2500, 25, 128, 8192
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=21)
+    Po, Qo = P0.copy(), Q0.copy()
+    E = len(ev_u)
+    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    j = orc.sample_counter(9, 0, ev_u, n, data['indptr'], data['indices'])
+    nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+    for sampler, stage in [(0, 1), (1, 1), (0, 0), (1, 0)]:
+        dev = Device(0, raise_errors=True)
+        dev.set_option('epoch_sampler', sampler)
+        dev.set_option('round_stage', stage)
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        nll, _, _ = dev.bpr_epoch(9, 0, W, 0.02, 0.01, 0.01)
+        P, Q = dev.get_factors()
         dev.close()
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (sampler, stage)
 
 
 def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):

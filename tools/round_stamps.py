@@ -24,8 +24,6 @@ ap.add_argument('--round', type=int, default=32768)
 ap.add_argument('--stage', type=int, default=1)
 ap.add_argument('--tpw', type=int, default=0)
 ap.add_argument('--launch', type=int, default=700)
-ap.add_argument('--layout', type=int, default=0)
-ap.add_argument('--flags', type=str, default='', help='comma list of debug_flags values: epoch time with parts of the kernel switched off')
 args = ap.parse_args()
 
 _shim.LIB_PATH = os.path.join(ROOT, 'yue_amd', 'csrc', 'libyue_hip_stamps.so')
@@ -37,19 +35,7 @@ dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i
 dev.set_option('round_stage', args.stage)
 if args.tpw:
     dev.set_option('round_tpw', args.tpw)
-dev.set_option('round_layout', args.layout)
 dev.bpr_epoch(1, 0, args.round, 0.02, 0.01, 0.01)          # warm
-if args.flags:
-    import time
-    for fl in [0] + [int(x) for x in args.flags.split(',')]:
-        dev.set_option('debug_flags', fl)
-        dev.bpr_epoch(1, 1, args.round, 0.02, 0.01, 0.01)
-        t = time.perf_counter()
-        dev.bpr_epoch(1, 2, args.round, 0.02, 0.01, 0.01)
-        dt = time.perf_counter() - t
-        print('debug_flags %2d: epoch %.1f ms  (%.2f ns/event)' % (fl, dt * 1e3, dt * 1e9 / (args.users * args.d)))
-    dev.set_option('debug_flags', 0)
-    sys.exit(0)
 dev.set_option('debug_stamp_launch', args.launch)
 dev.bpr_epoch(1, 1, args.round, 0.02, 0.01, 0.01)
 lib = _shim.load_library()

@@ -24,7 +24,6 @@ struct TrainArgs {
 #ifdef YUE_STAMPS
     unsigned long long *stamps;  // diagnostic build only (make stamps): 8 phase time stamps per update wave, then per prep block
     long long stamp_waves;
-    int dbg;                     // timing experiments (results become wrong): 1 every row in place, 2 no retire, 4 no dP flush, 8 no count loads, 16 no prep role
 #endif
     const int32_t *ev_u, *ev_i;
     int32_t *ev_j;
@@ -224,40 +223,6 @@ constexpr unsigned long long kTouch = 0x100000001ull;      // +1 touch in both h
 constexpr int kRsrcFlags = 0x00020000;
 constexpr unsigned kStageMax = 4;                          // touches per row served by the staging rows
 
-// Prep role of a round launch (blocks [0, prep_blocks)): one thread per event of the NEXT round --
-// draw the negative, take a ticket on both item rows (count + staging slot table), count the
-// user-row flushes (one per run of equal users inside a TPW-aligned batch).
-template <int TPW>
-__device__ __forceinline__ void round_prep_role(const TrainArgs &a, const RoundArgs &ra) {
-#ifdef YUE_STAMPS
-    if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8] = wall_clock64();
-#endif
-    const int64_t e = ra.n_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < ra.n_end) {
-        const int32_t i = a.ev_i[e];
-        int32_t j;
-        if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
-        else j = a.ev_j[e];
-        if (j >= 0) {
-            // the low half before the add is this touch's ticket on its row
-            const uint32_t ti = (uint32_t)atomicAdd(ra.cnt_next + i, kTouch), tj = (uint32_t)atomicAdd(ra.cnt_next + j, kTouch);
-            if (ra.staged) {
-                const uint32_t slot = 2u * (uint32_t)(e - ra.n_begin);
-                if (ti < kStageMax) ra.tab_next[(size_t)i * kStageMax + ti] = slot;
-                if (tj < kStageMax) ra.tab_next[(size_t)j * kStageMax + tj] = slot + 1u;
-            }
-        }
-        if (ra.apply_p) {      // one flush per run of equal users inside a TPW-aligned batch
-            const int32_t u = a.ev_u[e];
-            if ((e - ra.n_begin) % TPW == 0 || a.ev_u[e - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
-        }
-    }
-#ifdef YUE_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8 + 7] = wall_clock64();
-#endif
-}
-
 // evu / evi / evj: the event arrays again, as restrict-qualified read-only views of THIS round's
 // range, so that the wave-uniform reads of a batch's (u, i, j) become scalar loads (s_load): they do
 // not queue behind the vector-memory traffic of the other waves.  (The prep role writes ev_j of the
@@ -266,7 +231,36 @@ template <int KR, int TPW>
 __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const int32_t *__restrict__ evu,
                                                const int32_t *__restrict__ evi, const int32_t *__restrict__ evj) {
     const int lane = threadIdx.x & 63;
-    if ((int)blockIdx.x < ra.prep_blocks) { round_prep_role<TPW>(a, ra); return; }
+    if ((int)blockIdx.x < ra.prep_blocks) {
+#ifdef YUE_STAMPS
+        if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8] = wall_clock64();
+#endif
+        const int64_t e = ra.n_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e < ra.n_end) {
+            const int32_t i = a.ev_i[e];
+            int32_t j;
+            if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
+            else j = a.ev_j[e];
+            if (j >= 0) {
+                // the low half before the add is this touch's ticket on its row
+                const uint32_t ti = (uint32_t)atomicAdd(ra.cnt_next + i, kTouch), tj = (uint32_t)atomicAdd(ra.cnt_next + j, kTouch);
+                if (ra.staged) {
+                    const uint32_t slot = 2u * (uint32_t)(e - ra.n_begin);
+                    if (ti < kStageMax) ra.tab_next[(size_t)i * kStageMax + ti] = slot;
+                    if (tj < kStageMax) ra.tab_next[(size_t)j * kStageMax + tj] = slot + 1u;
+                }
+            }
+            if (ra.apply_p) {      // one flush per run of equal users inside a TPW-aligned batch
+                const int32_t u = a.ev_u[e];
+                if ((e - ra.n_begin) % TPW == 0 || a.ev_u[e - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
+            }
+        }
+#ifdef YUE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8 + 7] = wall_clock64();
+#endif
+        return;
+    }
     const int64_t wave = (int64_t)(blockIdx.x - ra.prep_blocks) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t base = ra.e_begin + wave * TPW;
     if (base >= ra.e_end) return;
@@ -503,278 +497,6 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
 #pragma unroll
     for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
     if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);
-}
-
-// ------------------------------------------------------------------------------------------
-// S-round launch, quarter-wave layout (k a multiple of 4): a wave is four groups of 16 lanes, each
-// group owns one event, lane h of a group holds floats [4h + 64v, 4h + 64v + 4) of P[u], Q[i],
-// Q[j] (v < KV).  Every gather / store is one 16-byte-per-lane buffer op covering 256 contiguous
-// bytes of four different rows; the row, its touch class and its target offset are per-lane values,
-// so nothing of the per-event control flow runs on the scalar unit (the full-wave kernel above
-// spends more scalar than vector instructions on it).  A workgroup = 4 waves = kBlockEvents
-// consecutive events.
-//   dot order: each lane adds its 4*KV products in element order, then a 16-lane butterfly
-//   (partner h^1, ^2, ^4, ^8).  Same semantics and same update arithmetic as k_round.
-// Item rows: touched once -> new row stored in place; 2..kStageMax touches -> the new row goes
-// to the touch's staging row (staging rows sit behind Q in the same buffer, so it is the same
-// store with another offset), the last toucher adds (staged - old) in event order; hotter rows ->
-// float atomics into dQ.
-// User rows: the differences of a run of equal users inside the workgroup's events are summed in
-// LDS (ds_add_f32); one wave per run flushes the sum into dP with 256-byte atomic instructions and
-// retires the run (last-arriver rule on cntp, which counts runs per kBlockEvents-aligned batch).
-// ------------------------------------------------------------------------------------------
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-#define YUE_BL4(rs, vo) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128((rs), (vo), 0, 0))
-#define YUE_BL4_SC1(rs, vo) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128((rs), (vo), 0, 16))
-#define YUE_BS4(val, rs, vo) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, (val)), (rs), (vo), 0, 0)
-#define YUE_BS4_SC1(val, rs, vo) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, (val)), (rs), (vo), 0, 16)
-constexpr int kBlockEvents = 16;                           // events of one workgroup of k_round_q
-
-__device__ __forceinline__ float row16_sum(float v) {      // butterfly over the 16 lanes of a group
-    v = v + dpp_mov<0xB1>(v);       // ^1
-    v = v + dpp_mov<0x4E>(v);       // ^2
-    v = v + dpp_mov<0x141>(v);      // ^4 (row_half_mirror: the value is constant over quads)
-    v = v + dpp_mov<0x140>(v);      // ^8 (row_mirror)
-    return v;
-}
-
-template <int KV>
-__global__ void __launch_bounds__(256) k_round_q(TrainArgs a, RoundArgs ra) {
-#ifdef YUE_STAMPS
-    if ((int)blockIdx.x < ra.prep_blocks && (a.dbg & 16)) return;
-#endif
-    if ((int)blockIdx.x < ra.prep_blocks) { round_prep_role<kBlockEvents>(a, ra); return; }
-    __shared__ int lds_user[kBlockEvents];               // user of every event of the workgroup (-1: no event)
-    __shared__ int lds_run_user[kBlockEvents];           // user of every run
-    __shared__ float lds_dp[kBlockEvents][KV * 64];      // summed user-row differences per run
-    const int lane = threadIdx.x & 63, g = lane >> 4, h = lane & 15;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t wave = (int64_t)(blockIdx.x - ra.prep_blocks) * 4 + wv;
-    const int64_t block_base = ra.e_begin + (int64_t)(blockIdx.x - ra.prep_blocks) * kBlockEvents;   // < e_end by the grid size
-    const int my_ix = wv * 4 + g;                        // my group's event inside the workgroup
-    YUE_STAMP(0, "");
-
-    const int64_t e = block_base + my_ix;
-    const bool ex = e < ra.e_end;
-    const int64_t ee = ex ? e : ra.e_end - 1;
-    const int u = a.ev_u[ee], i = a.ev_i[ee], j = ex ? a.ev_j[ee] : -1;
-    const bool ok = j >= 0;                              // no event / sampler gave up: nothing is written
-    if (h == 0) lds_user[my_ix] = ex ? u : -1;
-    for (int t = threadIdx.x; t < kBlockEvents * KV * 64; t += 256) (&lds_dp[0][0])[t] = 0.0f;
-    YUE_STAMP(1, "s_waitcnt vmcnt(0)");
-    uint32_t ci = 0u, cj = 0u;                           // touches of my rows in this round (the immutable half of the counter word)
-#ifdef YUE_STAMPS
-    if (a.dbg & 8) ci = cj = 1u; else
-#endif
-    if (ok) { ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32); }
-#ifdef YUE_STAMPS
-    if (a.dbg & 1) ci = cj = 1u;
-#endif
-
-    const unsigned k = (unsigned)a.k, row_bytes = k * 4u;
-    unsigned lb[KV];
-    bool lv[KV];
-#pragma unroll
-    for (int v = 0; v < KV; ++v) { lb[v] = (unsigned)h * 16u + 256u * v; lv[v] = 4u * h + 64u * v < k; }
-#define YUE_VO(pred, rowoff, v) (((pred) && lv[v] ? (rowoff) : kOobOffset) + lb[v])
-
-    __syncthreads();                                     // lds_user complete, lds_dp zeroed
-    // runs of equal users inside the workgroup; users of one workgroup are neighbours: P / dP are
-    // addressed relative to the smallest one
-    int rid = 0, nruns = 1;
-    unsigned u0 = 0xffffffffu;
-    {
-        int prev = lds_user[0];
-        u0 = prev >= 0 ? (unsigned)prev : u0;
-#pragma unroll
-        for (int t = 1; t < kBlockEvents; ++t) {
-            const int cur = lds_user[t];
-            const bool brk = cur != prev;
-            nruns += brk; rid += brk && t <= my_ix;
-            if (cur >= 0) u0 = min(u0, (unsigned)cur);
-            prev = cur;
-        }
-    }
-    if (h == 0 && (my_ix == 0 || lds_user[my_ix - (my_ix > 0)] != lds_user[my_ix])) lds_run_user[rid] = lds_user[my_ix];
-    u0 = (unsigned)__builtin_amdgcn_readfirstlane((int)u0);
-    nruns = __builtin_amdgcn_readfirstlane(nruns);
-
-    const unsigned n_events = (unsigned)(ra.e_end - ra.e_begin);
-    const unsigned q_bytes = (unsigned)a.n * row_bytes;                        // staging rows start here
-    const uint64_t pbytes = (uint64_t)(a.m - u0) * row_bytes;
-    const int prec = (int)(pbytes < 0x7fffffffull ? pbytes : 0x7fffffffull);
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(a.Q, 0, (int)(q_bytes + (ra.staged ? 2u * n_events * row_bytes : 0u)), kRsrcFlags);
-    const auto rsdQ = __builtin_amdgcn_make_buffer_rsrc(a.dQ, 0, (int)q_bytes, kRsrcFlags);
-    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.P + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
-    const auto rsdP = __builtin_amdgcn_make_buffer_rsrc(a.dP + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
-
-    const unsigned oi = (unsigned)i * row_bytes, oj = (ok ? (unsigned)j : 0u) * row_bytes, ou = (ex ? (unsigned)u - u0 : 0u) * row_bytes;
-    f4 qi[KV], qj[KV], p[KV];
-#pragma unroll
-    for (int v = 0; v < KV; ++v) {
-        qi[v] = YUE_BL4(rsQ, YUE_VO(true, oi, v));
-        qj[v] = YUE_BL4(rsQ, YUE_VO(true, oj, v));
-        p[v] = YUE_BL4(rsP, YUE_VO(true, ou, v));
-    }
-    YUE_STAMP(2, "s_waitcnt vmcnt(0)");
-
-    float ai = 0.0f, aj = 0.0f;
-#pragma unroll
-    for (int v = 0; v < KV; ++v)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float a1 = p[v][c] * qi[v][c]; ai = ai + a1;
-            const float a2 = p[v][c] * qj[v][c]; aj = aj + a2;
-        }
-    const float x = row16_sum(ai) - row16_sum(aj);                  // BPR.py:50, fp32 margin
-    const double sg = 1.0 / (1.0 + exp(-(double)x));                // qmath.py:115-116
-    const float cf = (float)(a.lr * (1.0 - sg));
-    double nll = (h == 0 && ok) ? -log(sg) : 0.0;                   // BPR.py:58
-    YUE_STAMP(3, "");
-
-    {
-        const bool uniq_i = ci == 1u, uniq_j = cj == 1u;
-        const bool stg_i = ra.staged && ci <= kStageMax, stg_j = ra.staged && cj <= kStageMax;
-        const bool wr_i = ok && (uniq_i || stg_i), wr_j = ok && (uniq_j || stg_j);
-        const unsigned slot = q_bytes + 2u * (unsigned)(e - ra.e_begin) * row_bytes;     // my two staging rows
-        const unsigned wi = uniq_i ? oi : slot, wj = uniq_j ? oj : slot + row_bytes;
-        const bool hot = __any(ok && !(wr_i && wr_j));              // a row with more than kStageMax touches
-#pragma unroll
-        for (int v = 0; v < KV; ++v) {
-            f4 ni, nj;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const Elem o = bpr_elem(p[v][c], qi[v][c], qj[v][c], cf, a.ru, a.ri);
-                ni[c] = o.qi2; nj[c] = o.qj2;
-                if (ok && lv[v]) atomicAdd(&lds_dp[rid][4 * h + 64 * v + c], o.p2 - p[v][c]);      // ds_add_f32
-            }
-            YUE_BS4_SC1(ni, rsQ, YUE_VO(wr_i, wi, v));
-            YUE_BS4_SC1(nj, rsQ, YUE_VO(wr_j, wj, v));
-            if (hot) {                                   // float atomics into dQ (wave-uniform branch, rare)
-                const bool hot_i = ok && !wr_i, hot_j = ok && !wr_j;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(ni[c] - qi[v][c], rsdQ, YUE_VO(hot_i, oi, v) + 4u * c, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(nj[c] - qj[v][c], rsdQ, YUE_VO(hot_j, oj, v) + 4u * c, 0, 0);
-                }
-            }
-        }
-        if (ok && h == 0 && uniq_i) ra.cnt_cur[i] = 0ull;           // sole toucher: reset the counter here
-        if (ok && h == 1 && uniq_j) ra.cnt_cur[j] = 0ull;
-    }
-    __syncthreads();                                     // every run's sum is complete in LDS
-
-    // Retire.  Role lanes: h = 0 -> my group's item row i, h = 1 -> row j; lane 16q + 2 -> the q-th
-    // run this wave flushes (run r goes to wave r % 4).
-    unsigned wrow = 0u, wcnt = 0u, wkind = 3u;
-    bool dec_q = false, dec_p = false;
-    if (h == 0) { wrow = (unsigned)i; wcnt = ci; wkind = 0u; dec_q = ok && ci != 1u; }
-    if (h == 1) { wrow = (unsigned)j; wcnt = cj; wkind = 1u; dec_q = ok && cj != 1u; }
-#ifdef YUE_STAMPS
-    if (!(a.dbg & 4))
-#endif
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = wv + 4 * q;
-        if (r < nruns) {                                 // wave-uniform
-            const int ru = lds_run_user[r];
-            if (ru >= 0) {
-#pragma unroll
-                for (int v = 0; v < KV; ++v) {
-                    const float tot = lds_dp[r][lane + 64 * v];
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, rsdP, ((unsigned)lane + 64u * v < k ? ((unsigned)ru - u0) * row_bytes : kOobOffset) + 4u * lane + 256u * v, 0, 0);
-                }
-                if (ra.apply_p && lane == 16 * q + 2) { wrow = (unsigned)ru; wkind = 2u; dec_p = true; }
-            }
-        }
-    }
-    YUE_STAMP(4, "");
-    // the row's staging slots (written by the previous launch): fetched behind the drain of my stores
-    u4 wslots = u4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    if (dec_q && ra.staged && wcnt <= kStageMax) wslots = *reinterpret_cast<const u4 *>(ra.tab_cur + (size_t)wrow * kStageMax);
-#ifdef YUE_STAMPS
-    if (a.dbg & 2) { dec_q = false; dec_p = false; }
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    YUE_STAMP(5, "");
-    bool last = false;
-    if (dec_q) last = (uint32_t)atomicAdd(ra.cnt_cur + wrow, ~0ull) == 1u;     // -1 on the low half
-    if (dec_p) last = atomicSub(ra.cntp_cur + wrow, 1u) == 1u;
-    unsigned long long win = __ballot(last);
-    YUE_STAMP(6, "s_waitcnt vmcnt(0)");
-    while (win) {
-        // the next four winners, one per group
-        int src = -1;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int b = win ? __ffsll((long long)win) - 1 : -1;
-            if (win) win &= win - 1;
-            if (t == g) src = b;
-        }
-        const bool have = src >= 0;
-        const int sl = have ? src : lane;
-        const unsigned row = (unsigned)__shfl((int)wrow, sl), cnt = (unsigned)__shfl((int)wcnt, sl), kind = (unsigned)__shfl((int)wkind, sl);
-        unsigned sq[4] = {(unsigned)__shfl((int)wslots[0], sl), (unsigned)__shfl((int)wslots[1], sl),
-                          (unsigned)__shfl((int)wslots[2], sl), (unsigned)__shfl((int)wslots[3], sl)};
-        const bool is_q = have && kind < 2u, is_p = have && kind == 2u;
-        const bool stg = is_q && ra.staged && cnt <= kStageMax;
-        // entries beyond the count are leftovers of earlier rounds; ascending slots = event order = the oracle's order
-#pragma unroll
-        for (unsigned q = 0; q < 4; ++q) if (q >= cnt) sq[q] = 0xffffffffu;
-#define YUE_CSWAP(x_, y_) { const unsigned lo_ = min(x_, y_), hi2_ = max(x_, y_); x_ = lo_; y_ = hi2_; }
-        YUE_CSWAP(sq[0], sq[1]) YUE_CSWAP(sq[2], sq[3]) YUE_CSWAP(sq[0], sq[2]) YUE_CSWAP(sq[1], sq[3]) YUE_CSWAP(sq[1], sq[2])
-#undef YUE_CSWAP
-        const unsigned oq = row * row_bytes, op = (is_p ? row - u0 : 0u) * row_bytes;
-        if (is_q && h == 0) ra.cnt_cur[row] = 0ull;      // every touch retired: clear the word
-        f4 xr[KV], d[KV];
-#pragma unroll
-        for (int v = 0; v < KV; ++v) {
-            const f4 xq = YUE_BL4(rsQ, YUE_VO(is_q, oq, v));
-            const f4 xp = YUE_BL4(rsP, YUE_VO(is_p, op, v));
-            xr[v] = is_q ? xq : xp;
-            d[v] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        // staged rows: every load of the staged bytes is an sc1 load issued after this wave's decrement returned
-        f4 st[4][KV];
-#pragma unroll
-        for (unsigned q = 0; q < 4; ++q)
-#pragma unroll
-            for (int v = 0; v < KV; ++v)
-                st[q][v] = YUE_BL4_SC1(rsQ, YUE_VO(stg && q < cnt, q_bytes + sq[q] * row_bytes, v));
-#pragma unroll
-        for (unsigned q = 0; q < 4; ++q)
-#pragma unroll
-            for (int v = 0; v < KV; ++v) {
-                const bool use = stg && q < cnt;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float dq = st[q][v][c] - xr[v][c];               // the toucher's (new - old), recomputed
-                    if (q == 0) d[v][c] = use ? dq : 0.0f;
-                    else d[v][c] = use ? d[v][c] + dq : d[v][c];
-                }
-            }
-        if (have && !stg) {                              // hot item row or user row: the sum sits in dQ / dP
-            float *dx = (is_q ? a.dQ : a.dP) + (uint64_t)row * k;
-#pragma unroll
-            for (int v = 0; v < KV; ++v)
-                if (lv[v]) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) d[v][c] = atomicExch(dx + 4 * h + 64 * v + c, 0.0f);
-                }
-        }
-#pragma unroll
-        for (int v = 0; v < KV; ++v) {
-            const f4 nx = xr[v] + d[v];
-            YUE_BS4(nx, rsQ, YUE_VO(is_q, oq, v));
-            YUE_BS4(nx, rsP, YUE_VO(is_p, op, v));
-        }
-    }
-    YUE_STAMP(7, "s_waitcnt vmcnt(0)");
-    nll += __shfl_xor(nll, 16);
-    nll += __shfl_xor(nll, 32);
-    if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);
-#undef YUE_VO
 }
 
 // Multi-GPU: after the all-reduce of dP[first .. first+count) the same range is applied everywhere.

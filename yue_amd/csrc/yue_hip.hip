@@ -70,7 +70,6 @@ struct yue_ctx {
 #ifdef YUE_STAMPS
     DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
     int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0, stamp_prep = 0;
-    int dbg_flags = 0;
 #endif
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
@@ -90,7 +89,6 @@ struct yue_ctx {
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
     int opt_epoch_sampler = 0;           // 0: negatives of an epoch drawn by one pass up front; 1: by the round launches (fused)
-    int opt_round_layout = 0;            // 0: quarter-wave round kernel where k % 4 == 0; 1: always the full-wave kernel
     // kernel timing
     int timing_stride = 0;
     int64_t launch_counter = 0;
@@ -140,12 +138,6 @@ int tpw_of(const yue_ctx *c) {
     return kr_of(c->k) == 4 ? 4 : 8;      // measured on C3 (k=128): 8 events per wave 53.9 ms/epoch, 4 -> 58.7 ms
 }
 
-// k % 4 == 0: the quarter-wave round kernel (4 events per wave, 16 per workgroup) unless the caller asked for
-// the full-wave one (option round_layout 1, or an explicit round_tpw other than 4)
-bool quarter_layout(const yue_ctx *c) {
-    return c->opt_round_layout == 0 && c->k % 4 == 0 && (c->opt_round_tpw == 0 || c->opt_round_tpw == 4);
-}
-
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
 // Every timing_stride-th launch is bracketed with HIP events on the library's stream.
 int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
@@ -159,8 +151,7 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1]; ra.staged = c->staged ? 1 : 0;
     ra.sample_next = sample_next; ra.apply_p = apply_p;
     ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
-    const bool quarter = quarter_layout(c);
-    const int tpw = quarter ? 4 : tpw_of(c);
+    const int tpw = tpw_of(c);
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
     const int64_t blocks = ra.prep_blocks + (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
@@ -179,7 +170,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 #ifdef YUE_STAMPS
     yue::TrainArgs a = a_in;
     a.stamps = nullptr;
-    a.dbg = c->dbg_flags;
     if (e1 > e0 && c->update_launches++ == c->stamp_launch) {
         HIPCHK(c->stamps.resize((size_t)(waves + ra.prep_blocks) * 8));
         HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)(waves + ra.prep_blocks) * 64, c->stream));
@@ -191,13 +181,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 #else
     const yue::TrainArgs &a = a_in;
 #endif
-    if (quarter) {
-        switch (kr_of(c->k)) {
-            case 1: hipLaunchKernelGGL((yue::k_round_q<1>), grid, block, 0, c->stream, a, ra); break;
-            case 2: hipLaunchKernelGGL((yue::k_round_q<2>), grid, block, 0, c->stream, a, ra); break;
-            default: hipLaunchKernelGGL((yue::k_round_q<4>), grid, block, 0, c->stream, a, ra); break;
-        }
-    } else
     switch (kr_of(c->k) * 16 + tpw) {
         case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round<2, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
@@ -477,7 +460,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     for (int64_t r = 0; r < n_rounds; ++r) if (round_ptr[r + 1] < round_ptr[r]) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr must be non-decreasing");
     if (c->m * (int64_t)c->k * 4 >= (1ll << 31)) {
         // the round kernel addresses P relative to the smallest user of a wave's batch with 31-bit offsets
-        const int tpw = quarter_layout(c) ? yue::kBlockEvents : tpw_of(c);
+        const int tpw = tpw_of(c);
         for (int64_t r = 0; r < n_rounds; ++r)
             for (int64_t b = round_ptr[r]; b < round_ptr[r + 1]; b += tpw) {
                 int32_t lo = u[b], hi = u[b];
@@ -623,13 +606,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
     if (key == "epoch_sampler") { c->opt_epoch_sampler = value != 0; return YUE_OK; }
-    if (key == "round_layout") {
-        if (value != 0 && value != 1) return fail(YUE_ERR_ARG, "yue_set_option: round_layout must be 0 (quarter-wave where k % 4 == 0) or 1 (full-wave)");
-        c->opt_round_layout = (int)value;
-        return YUE_OK;
-    }
 #ifdef YUE_STAMPS
-    if (key == "debug_flags") { c->dbg_flags = (int)value; return YUE_OK; }
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
 #endif
     if (key == "round_tpw") {
