@@ -238,6 +238,47 @@ def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):
     assert np.array_equal(P[1], P0[1])
 
 
+def test_user_factors_beyond_two_gib(orc):
+    # BASELINE config 4 keeps 10M x 128 user factors (5 GB) on every GPU: the round kernel addresses P and
+    # dP with 31-bit offsets relative to the smallest user of a wave's batch.  Here 4.3M users x 128 = 2.2 GB.
+    from yue_amd._shim import Device
+    m, n, d, k, W = 4300000, 2000, 2, 128, 32768
+    data = synth.make_arrays(m, n, d, seed=31)
+    rng = np.random.default_rng(32)
+    P0 = rng.random((m, k), dtype=np.float32) / 10
+    Q0 = rng.random((n, k), dtype=np.float32) / 10
+    assert P0.nbytes > (1 << 31)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    E = len(ev_u)
+    dev = Device(0, raise_errors=True)
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        j = orc.sample_counter(6, 0, ev_u, n, data['indptr'], data['indices'])
+        nll, sp, _ = dev.bpr_epoch(6, 0, W, 0.02, 0.01, 0.01)
+        P, Q = dev.get_factors()
+        Po, Qo = P0.copy(), Q0.copy()
+        rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+        assert rel_err(P[-1000:], Po[-1000:]) < TOL and not np.array_equal(P[-1000:], P0[-1000:])
+        assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp
+        # explicit rounds over the last users (offsets above 2 GiB), ungrouped order inside the rounds
+        T = 40000
+        perm = np.random.RandomState(1).permutation(T)
+        u2, i2, j2 = ev_u[E - T:][perm], data['ev_i'][E - T:][perm], j[E - T:][perm]
+        rp2 = np.array([0, 15000, T], np.int64)
+        dev.set_factors(P0, Q0)
+        nll2 = dev.bpr_rounds(u2, i2, j2, rp2, 0.02, 0.01, 0.01)
+        P, Q = dev.get_factors()
+        Po[:] = P0
+        Qo[:] = Q0
+        nll2_o = orc.bpr_rounds(Po, Qo, u2, i2, j2, rp2, 0.02, 0.01, 0.01)
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll2 - nll2_o) <= 1e-9 * abs(nll2_o)
+    finally:
+        dev.close()
+
+
 def test_full_size_properties(dev):
     # BASELINE config 2 shape (100K x 50K, k=64): size-independent properties instead of the oracle
     m, n, d, k = 100000, 50000, 50, 64
