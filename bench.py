@@ -47,9 +47,13 @@ def algorithmic_bytes(k):
     return 24 * k + 8
 
 
-def cpu_baseline(data, P0, Q0, j_first, k, budget_s=15.0):
-    """oracle/bpr_oracle.c sequential loop (the reference's semantics) on one core, bounded sample."""
+def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
+    """The reference's sequential loop on the host, bounded samples of the same workload:
+    `value` = oracle/bpr_oracle.c on one core (exact semantics); beside it the loop as NumPy runs it
+    (oracle/numpy_loop.py, what the reference executes per triplet minus its dict lookups) and the C
+    loop raced Hogwild-style by the box's CPU share."""
     import oracle
+    from oracle.numpy_loop import bpr_loop
     orc = oracle.Oracle()
     ev_u = np.repeat(np.arange(data['m'], dtype=np.int32), np.diff(data['ev_ptr']))
     probe = min(len(j_first), 200000)
@@ -62,9 +66,27 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=15.0):
     t0 = time.perf_counter()
     orc.bpr_sequential(P, Q, ev_u[:S], data['ev_i'][:S], j_first[:S], LR, REG_U, REG_I)
     dt = time.perf_counter() - t0
+    # NumPy loop: ~1e5 triplets/s
+    Sn = min(len(j_first), 300000)
+    P, Q = P0.copy(), Q0.copy()
+    t0 = time.perf_counter()
+    bpr_loop(P, Q, ev_u[:Sn], data['ev_i'][:Sn], j_first[:Sn], LR, REG_U, REG_I)
+    dtn = time.perf_counter() - t0
+    # Hogwild with the threads this process may use (16 per GPU on the bench boxes)
+    try:
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        threads = max(1, min(16, os.cpu_count() or 1))
+    Sh = int(min(len(j_first), max(probe, rate * threads * 4.0)))
+    P, Q = P0.copy(), Q0.copy()
+    t0 = time.perf_counter()
+    orc.bpr_hogwild(P, Q, ev_u[:Sh], data['ev_i'][:Sh], j_first[:Sh], LR, REG_U, REG_I, threads)
+    dth = time.perf_counter() - t0
     return {'value': S / dt, 'unit': 'triplets/s', 'cores': 1, 'kind': 'port',
             'sample': 'first %d triplets of epoch 0 of the same workload, sequential loop of oracle/bpr_oracle.c '
-                      '(restates recommender/cf/BPR.py:42-58), %.1f s on %s' % (S, dt, _cpu_name())}
+                      '(restates recommender/cf/BPR.py:42-58), %.1f s on %s' % (S, dt, _cpu_name()),
+            'numpy_loop': {'value': Sn / dtn, 'cores': 1, 'sample': 'first %d triplets, oracle/numpy_loop.py (the per-triplet NumPy statements of BPR.py:50-58; bit-equal to the reference on its goldens), %.1f s' % (Sn, dtn)},
+            'hogwild': {'value': Sh / dth, 'cores': threads, 'sample': 'first %d triplets, the C loop raced by %d threads over slices of the stream (result depends on the interleaving), %.1f s' % (Sh, threads, dth)}}
 
 
 def measured_traffic(workload, round_events):

@@ -229,6 +229,33 @@ double orc_bpr_sequential(float *P, float *Q, int k, const int32_t *u, const int
 }
 
 /*
+ * Timing baseline only (bench.py cpu_baseline): the same loop run Hogwild-style by
+ * `threads` threads, each over a contiguous slice of the triplet stream, racing on shared rows.
+ * Not a checker: its result depends on the interleaving.
+ */
+#include <pthread.h>
+typedef struct { float *P, *Q; int k; const int32_t *u, *i, *j; int64_t t0, t1; double lr, regU, regI, nll; } hog_t;
+static void *hog_run(void *arg) {
+    hog_t *h = (hog_t *)arg;
+    h->nll = orc_bpr_sequential(h->P, h->Q, h->k, h->u + h->t0, h->i + h->t0, h->j + h->t0, h->t1 - h->t0, h->lr, h->regU, h->regI);
+    return NULL;
+}
+double orc_bpr_hogwild(float *P, float *Q, int k, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
+                       double lr, double regU, double regI, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t tid[256];
+    hog_t job[256];
+    for (int t = 0; t < threads; t++) {
+        job[t] = (hog_t){ P, Q, k, u, i, j, T * t / threads, T * (t + 1) / threads, lr, regU, regI, 0.0 };
+        pthread_create(&tid[t], NULL, hog_run, &job[t]);
+    }
+    double nll = 0.0;
+    for (int t = 0; t < threads; t++) { pthread_join(tid[t], NULL); nll += job[t].nll; }
+    return nll;
+}
+
+/*
  * Round semantics S-round (ours): events are cut into consecutive rounds
  * round_ptr[r]..round_ptr[r+1].  Inside a round every triplet's update is the reference
  * update (above) evaluated on the factors as they were when the round started; the

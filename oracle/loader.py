@@ -31,6 +31,7 @@ class Oracle(object):
         L.orc_sample_python.restype = C.c_int64
         L.orc_bpr_sequential.restype = C.c_double
         L.orc_bpr_rounds.restype = C.c_double
+        L.orc_bpr_hogwild.restype = C.c_double
         L.orc_sumsq.restype = C.c_double
         L.orc_bpr_round_deltas.restype = C.c_double
         L.orc_topn_scan.restype = C.c_int
@@ -65,6 +66,13 @@ class Oracle(object):
         u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
         return self.lib.orc_bpr_sequential(_p(P, C.c_float), _p(Q, C.c_float), C.c_int(P.shape[1]), _p(u, C.c_int32), _p(i, C.c_int32),
                                            _p(j, C.c_int32), C.c_int64(len(u)), C.c_double(lr), C.c_double(regU), C.c_double(regI))
+
+    def bpr_hogwild(self, P, Q, u, i, j, lr, regU, regI, threads):
+        """Timing baseline: the sequential loop raced by `threads` threads over slices of the stream."""
+        assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous
+        u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
+        return self.lib.orc_bpr_hogwild(_p(P, C.c_float), _p(Q, C.c_float), C.c_int(P.shape[1]), _p(u, C.c_int32), _p(i, C.c_int32),
+                                        _p(j, C.c_int32), C.c_int64(len(u)), C.c_double(lr), C.c_double(regU), C.c_double(regI), C.c_int(threads))
 
     def bpr_rounds(self, P, Q, u, i, j, round_ptr, lr, regU, regI):
         assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous

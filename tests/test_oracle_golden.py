@@ -53,6 +53,37 @@ def test_sequential_epochs_match_reference(orc, tag):
     assert abs(lr - float(z['lRate'])) < 1e-12
 
 
+@pytest.mark.parametrize('tag', ['c1_k10_e1', 'd2_k64_e1', 'd3_k128_e2'])
+def test_numpy_restatement_lands_on_the_reference_bit_for_bit(orc, tag):
+    # oracle/numpy_loop.py issues the same NumPy operations as BPR.py:50-58 -> identical factors on this NumPy
+    # build; the C oracle (own dot order) stays within 1e-6 of it.  (Learning rate: unchanged after iteration 1.)
+    from oracle.numpy_loop import bpr_loop
+    z, meta, iters, E = _case(tag)
+    m, n, k, seed = int(z['m']), int(z['n']), int(z['k']), int(z['seed'])
+    P, Q = synth.init_factors(m, n, k, seed)
+    Pc, Qc = P.copy(), Q.copy()
+    for ep in range(iters):
+        sl = slice(ep * E, (ep + 1) * E)
+        nll = bpr_loop(P, Q, z['u'][sl], z['i'][sl], z['j'][sl], 0.02, 0.01, 0.01)
+        nll_c = orc.bpr_sequential(Pc, Qc, z['u'][sl], z['i'][sl], z['j'][sl], 0.02, 0.01, 0.01)
+        assert abs(nll - nll_c) <= 1e-6 * abs(nll)
+    assert np.array_equal(P, z['P']) and np.array_equal(Q, z['Q'])
+    assert rel_err(Pc, P) < 1e-6 and rel_err(Qc, Q) < 1e-6
+
+
+def test_hogwild_baseline_with_one_thread_is_the_sequential_loop(orc):
+    z, _, iters, E = _case('d2_k64_e1')
+    m, n, k, seed = int(z['m']), int(z['n']), int(z['k']), int(z['seed'])
+    P, Q = synth.init_factors(m, n, k, seed)
+    P2, Q2 = P.copy(), Q.copy()
+    a = orc.bpr_sequential(P, Q, z['u'][:E], z['i'][:E], z['j'][:E], 0.02, 0.01, 0.01)
+    b = orc.bpr_hogwild(P2, Q2, z['u'][:E], z['i'][:E], z['j'][:E], 0.02, 0.01, 0.01, 1)
+    assert a == b and np.array_equal(P, P2) and np.array_equal(Q, Q2)
+    P3, Q3 = synth.init_factors(m, n, k, seed)
+    c = orc.bpr_hogwild(P3, Q3, z['u'][:E], z['i'][:E], z['j'][:E], 0.02, 0.01, 0.01, 4)     # races: close, not equal
+    assert abs(c - a) < 0.05 * abs(a) and np.isfinite(P3).all() and np.isfinite(Q3).all()
+
+
 @pytest.mark.parametrize('tag,N', [('c1_top10', 10), ('c1_top20', 20)])
 def test_overwrite_scan_lists_match_reference(orc, tag, N):
     # IterativeRecommender.py:93-145 on the reference's own trained factors: integer lists identical
