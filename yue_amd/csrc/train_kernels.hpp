@@ -280,18 +280,7 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     for (int t = 0; t < TPW; ++t) if (lane == t) { i = hi_[t]; j = hj[t]; }
     YUE_STAMP(1, "s_waitcnt lgkmcnt(0)");
     uint32_t ci = 0, cj = 0;             // touches of my rows in this round (the immutable half)
-    uint32_t si[kStageMax], sj[kStageMax];       // staging slots of my rows' touches (sorted below)
-#pragma unroll
-    for (unsigned q = 0; q < kStageMax; ++q) si[q] = sj[q] = 0xffffffffu;
-    if (lane < TPW && j >= 0) {
-        ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32);
-        if (ra.staged) {
-            const uint4 wi = *reinterpret_cast<const uint4 *>(ra.tab_cur + (size_t)i * kStageMax);
-            const uint4 wj = *reinterpret_cast<const uint4 *>(ra.tab_cur + (size_t)j * kStageMax);
-            si[0] = wi.x; si[1] = wi.y; si[2] = wi.z; si[3] = wi.w;
-            sj[0] = wj.x; sj[1] = wj.y; sj[2] = wj.z; sj[3] = wj.w;
-        }
-    }
+    if (lane < TPW && j >= 0) { ci = (uint32_t)(ra.cnt_cur[i] >> 32); cj = (uint32_t)(ra.cnt_cur[j] >> 32); }
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = k * 4u;
     unsigned vo[KR];
@@ -353,16 +342,6 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     __builtin_amdgcn_sched_barrier(0);
 
     YUE_STAMP(3, "");
-    // entries beyond the row's touch count are leftovers of earlier rounds: drop them, then put the
-    // slots in ascending order = event order, the order in which the oracle sums a row's differences
-    static_assert(kStageMax == 4, "the sorting network below is written for four slots");
-#pragma unroll
-    for (unsigned q = 0; q < kStageMax; ++q) { if (q >= ci) si[q] = 0xffffffffu; if (q >= cj) sj[q] = 0xffffffffu; }
-#define YUE_CSWAP(x, y) { const uint32_t lo_ = min(x, y), hi2_ = max(x, y); x = lo_; y = hi2_; }
-    YUE_CSWAP(si[0], si[1]) YUE_CSWAP(si[2], si[3]) YUE_CSWAP(si[0], si[2]) YUE_CSWAP(si[1], si[3]) YUE_CSWAP(si[1], si[2])
-    YUE_CSWAP(sj[0], sj[1]) YUE_CSWAP(sj[2], sj[3]) YUE_CSWAP(sj[0], sj[2]) YUE_CSWAP(sj[1], sj[3]) YUE_CSWAP(sj[1], sj[2])
-#undef YUE_CSWAP
-
     float dp[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
@@ -416,8 +395,33 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
     // has been performed and every toucher has read the row: it swaps the sum out of dQ (returning
     // atomic: coherent at the memory side, leaves dQ zeroed) and rewrites the row.
     YUE_STAMP(4, "");
+    // staging slots of my contended rows (written by the previous launch): fetched behind the drain of
+    // my stores, only where a last toucher could need them (rows with 2..kStageMax touches)
+    uint32_t si[kStageMax], sj[kStageMax];
+#pragma unroll
+    for (unsigned q = 0; q < kStageMax; ++q) si[q] = sj[q] = 0xffffffffu;
+    if (ra.staged && lane < TPW && j >= 0) {
+        if (ci != 1u && ci <= kStageMax) {
+            const uint4 wi = *reinterpret_cast<const uint4 *>(ra.tab_cur + (size_t)i * kStageMax);
+            si[0] = wi.x; si[1] = wi.y; si[2] = wi.z; si[3] = wi.w;
+        }
+        if (cj != 1u && cj <= kStageMax) {
+            const uint4 wj = *reinterpret_cast<const uint4 *>(ra.tab_cur + (size_t)j * kStageMax);
+            sj[0] = wj.x; sj[1] = wj.y; sj[2] = wj.z; sj[3] = wj.w;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YUE_STAMP(5, "");
+    // entries beyond the row's touch count are leftovers of earlier rounds: drop them, then put the
+    // slots in ascending order = event order, the order in which the oracle sums a row's differences
+    static_assert(kStageMax == 4, "the sorting network below is written for four slots");
+#pragma unroll
+    for (unsigned q = 0; q < kStageMax; ++q) { if (q >= ci) si[q] = 0xffffffffu; if (q >= cj) sj[q] = 0xffffffffu; }
+#define YUE_CSWAP(x, y) { const uint32_t lo_ = min(x, y), hi2_ = max(x, y); x = lo_; y = hi2_; }
+    YUE_CSWAP(si[0], si[1]) YUE_CSWAP(si[2], si[3]) YUE_CSWAP(si[0], si[2]) YUE_CSWAP(si[1], si[3]) YUE_CSWAP(si[1], si[2])
+    YUE_CSWAP(sj[0], sj[1]) YUE_CSWAP(sj[2], sj[3]) YUE_CSWAP(sj[0], sj[2]) YUE_CSWAP(sj[1], sj[3]) YUE_CSWAP(sj[1], sj[2])
+#undef YUE_CSWAP
+
     bool last_i = false, last_j = false, last_p = false;
     if (lane < TPW && j >= 0) {
         if (ci != 1u) last_i = (uint32_t)atomicAdd(ra.cnt_cur + i, ~0ull) == 1u;     // -1 on the low half
