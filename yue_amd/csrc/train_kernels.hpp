@@ -186,14 +186,17 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 }
 
 // ------------------------------------------------------------------------------------------
-// S-round launch.  Blocks [0, prep_blocks) prepare the NEXT round (one thread per event: draw the
-// negative, count the two item-row touches).  The other blocks update THIS round: one wave takes
+// S-round launch.  Blocks [0, prep_blocks) prepare the NEXT round (one thread per event: take a
+// ticket on the two item rows = touch count + staging-slot table, count the user-row flushes; with
+// sample_next also draw the negative -- yue_bpr_epoch draws an epoch's negatives up front with
+// k_sample instead).  The other blocks update THIS round: one wave takes
 // TPW consecutive events, requests all their rows up front (straight-line code: the compiler's
 // counted waits keep every gather in flight), evaluates the TPW sigmoids in one double-precision
 // pass (lane t holds triplet t), then writes:
 //   * an item row touched exactly once in the round (cnt == 1): the new row, in place, plain
 //     stores -- nobody else reads or writes it this round;
-//   * a row with 2..kStageMax touches: (new - old) written to the touch's own staging row with
+//   * a row with 2..kStageMax touches: (new - old) written to the touch's own staging row (behind the
+//     item rows in the Q allocation) with
 //     write-through (sc1) stores; the last toucher of the row (touch count reaching zero: every other
 //     toucher has drained its stores before its decrement) reads the staged rows back with sc1 loads,
 //     adds them in event order -- the order of the oracle's sum -- and rewrites the row once.
