@@ -128,6 +128,26 @@ int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t
  *               the reference's order-dependent overwrite-scan */
 int yue_set_option(yue_ctx *ctx, const char *name, int64_t value);
 
+/*
+ * FISM (reference recommender/cf/FISM.py) -- parity path: the reference's strictly
+ * sequential epoch on the device, in the reference's types (item-history factors P float64 [n,k],
+ * item factors Q float32 [n,k], item bias Bi float64 [n]).
+ *   yue_fism_set_model / yue_fism_get_model   replace FISM.initModel's arrays (FISM.py:15-18) on / from the device
+ *   yue_fism_epoch   replaces one pass of FISM.buildModel's loop (FISM.py:38-69): users in user_ptr order, users
+ *                    with one event skipped; negs = the accepted negatives in processing order (rho per event,
+ *                    drawn by the caller as FISM.py:50-53 does); coef[u] = pow(nu - 1, -alpha) (FISM.py:42).
+ *                    Outputs: sum of 0.5*error^2 (:58) and {sum(P*P), sum(Q*Q), Bi.Bi} after the pass (:70).
+ *   yue_fism_scores  replaces FISM.predict (FISM.py:75-83) for a user whose training events are `items`.
+ *   yue_fism_topn_scan  predict + the selection of base/IterativeRecommender.py:98-145 for nu users given as a
+ *                    CSR of their training events (mask = those items).  YUE_ERR_FEW_ITEMS as yue_topn_scan.
+ */
+int yue_fism_set_model(yue_ctx *ctx, const double *P, const float *Q, const double *Bi, int64_t n, int k);
+int yue_fism_get_model(yue_ctx *ctx, double *P, float *Q, double *Bi);
+int yue_fism_epoch(yue_ctx *ctx, const int64_t *user_ptr, int64_t m, const int32_t *ev_i, const int32_t *negs, int64_t n_negs, int rho,
+                   const double *coef, double lr, double regI, double regB, double *half_sq_out, double *sumsq3_out);
+int yue_fism_scores(yue_ctx *ctx, const int32_t *items, int64_t n_items, double *out_n);
+int yue_fism_topn_scan(yue_ctx *ctx, const int64_t *row_ptr, const int32_t *row_items, int64_t nu, int N, int32_t *out_ids, double *out_scores);
+
 /* Multi-GPU (one process per GPU, RCCL over xGMI).  Rank 0 creates the id, the caller ships
  * the 128 bytes to the other ranks (any side channel), every rank calls yue_comm_init. */
 int yue_comm_unique_id(void *id128_out);

@@ -1,0 +1,128 @@
+"""GPU parity of the FISM path, through the C ABI: the device runs the reference's
+sequential epoch; compared with what the reference produced (tests/golden/g8_*) and with the NumPy oracle.
+Tolerances: the reference's BLAS dot order is not pinned, ours is a 64-lane butterfly in double ->
+float64 arrays within 1e-11 rel, the float32 Q within 1e-6 rel; printed lines and integer lists equal."""
+import glob
+import random
+
+import numpy as np
+import pytest
+
+from test_fism_golden import CASES, LR0, REG, bold_driver, fism_case
+from test_host_golden import _conf_text, _load
+from util import gj, gz, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from yue_amd._shim import Device
+    d = Device(0, raise_errors=True)
+    yield d
+    d.close()
+
+
+def coefs(ptr, alpha):
+    return np.array([pow(int(nu) - 1, -alpha) if nu > 1 else 0.0 for nu in np.diff(ptr)], np.float64)
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_epochs_match_reference(dev, tag):
+    z, meta, ptr = fism_case(tag)
+    iters, rho, alpha = int(z['iters']), int(z['rho']), float(z['alpha'])
+    dev.fism_set_model(z['P0'], z['Q0'], z['B0'])
+    per = len(z['negs']) // iters
+    lr, last = LR0, 0
+    for ep in range(iters):
+        half, sp, sq, sb = dev.fism_epoch(ptr, z['ev_i'], z['negs'][ep * per:(ep + 1) * per], rho, coefs(ptr, alpha), lr, REG, REG)
+        loss = np.float64(half) + (REG * np.float64(sp) + REG * np.float32(sq) + REG * np.float64(sb))
+        assert 'FISM [1] iteration %d: loss = %.4f, delta_loss = %.5f learning_Rate = %.5f' % (ep + 1, loss, last - loss, lr) == meta['lines'][ep]
+        lr = bold_driver(lr, last, loss, ep + 1)
+        last = loss
+    P, Q, Bi = np.empty_like(z['P']), np.empty_like(z['Q']), np.empty_like(z['Bi'])
+    dev.fism_get_model(P, Q, Bi)
+    assert rel_err(P, z['P']) < 1e-11 and rel_err(Bi, z['Bi']) < 1e-11 and rel_err(Q, z['Q']) < 1e-6
+    assert abs(loss - float(z['loss'])) < 1e-9 * abs(float(z['loss'])) and lr == float(z['lRate'])
+    # predict + selection on the trained model
+    tu, N = z['test_users'], z['rec_ids'].shape[1]
+    for t in range(16):
+        u = int(tu[t])
+        s = dev.fism_scores(z['ev_i'][ptr[u]:ptr[u + 1]])
+        assert np.abs(s - z['predict16'][t]).max() < 1e-12 * np.abs(z['predict16'][t]).max() + 1e-15
+    rows = [z['ev_i'][ptr[int(u)]:ptr[int(u) + 1]] for u in tu]
+    rp = np.zeros(len(rows) + 1, np.int64)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    ids, sc = dev.fism_topn_scan(rp, np.concatenate(rows), N)
+    assert np.array_equal(ids, z['rec_ids'])
+    assert (np.diff(sc, axis=1) <= 0).sum() >= 0            # scores are the slots' values (not necessarily sorted: overwrite-scan)
+
+
+def test_against_the_numpy_oracle_on_other_inputs(dev):
+    # ragged users (0, 1 and many events), duplicates inside a user, rho = 3, k = 200
+    from oracle.numpy_fism import fism_epoch, fism_scores, overwrite_scan
+    rng = np.random.RandomState(5)
+    n, k, rho, alpha = 90, 200, 3, 0.6
+    sizes = [0, 1, 5, 12, 1, 30, 2, 0, 7]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev_i = np.concatenate([rng.randint(0, n // 2, s) for s in sizes]).astype(np.int32)
+    negs = []
+    for u, s in enumerate(sizes):
+        if s > 1:
+            mine = set(ev_i[ptr[u]:ptr[u + 1]].tolist())
+            negs += [int(rng.choice([x for x in range(n) if x not in mine])) for _ in range(s * rho)]
+    negs = np.array(negs, np.int32)
+    P0, Q0, B0 = rng.rand(n, k) / 100, (rng.rand(n, k) / 10).astype(np.float32), rng.rand(n) / 100
+    dev.fism_set_model(P0, Q0, B0)
+    half, sp, sq, sb = dev.fism_epoch(ptr, ev_i, negs, rho, coefs(ptr, alpha), 0.02, 0.01, 0.03)
+    Po, Qo, Bo = P0.copy(), Q0.copy(), B0.copy()
+    half_o = fism_epoch(Po, Qo, Bo, ptr, ev_i, negs, rho, alpha, 0.02, 0.01, 0.03)
+    P, Q, Bi = np.empty_like(P0), np.empty_like(Q0), np.empty_like(B0)
+    dev.fism_get_model(P, Q, Bi)
+    assert rel_err(P, Po) < 1e-11 and rel_err(Bi, Bo) < 1e-11 and rel_err(Q, Qo) < 1e-6 and abs(half - half_o) < 1e-10 * half_o
+    assert abs(sp - (Po * Po).sum()) < 1e-10 * sp and abs(sb - Bo.dot(Bo)) < 1e-10 * sb and abs(sq - float((Qo.astype(np.float64) ** 2).sum())) < 1e-6 * sq
+    users = [2, 3, 5, 8]
+    rows = [ev_i[ptr[u]:ptr[u + 1]] for u in users]
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    ids, _ = dev.fism_topn_scan(rp, np.concatenate(rows), 10)
+    for t, r in enumerate(rows):
+        assert overwrite_scan(fism_scores(P, Q, Bi, r), r, 10)[0] == ids[t].tolist()
+    with pytest.raises(IndexError):                      # fewer than N candidates (reference: IndexError at :126)
+        dev.fism_topn_scan(np.array([0, n - 3], np.int64), np.arange(n - 3, dtype=np.int32), 10)
+    from yue_amd._shim import YueHipError
+    with pytest.raises(YueHipError):                     # wrong number of negatives
+        dev.fism_epoch(ptr, ev_i, negs[:-1], rho, coefs(ptr, alpha), 0.02, 0.01, 0.03)
+
+
+def test_through_the_plugin_surface(tmp_path, capsys):
+    # FISM.conf keys on the C1 log, driven as tools/make_goldens.py drives the reference's class
+    from yue_amd import synth
+    from yue_amd.recommender.cf.FISM import FISM
+    from yue_amd.tool.config import Config
+    z, meta = gz('g8_fism_c1_k10_e2.npz'), gj('g8_fism_c1_k10_e2.json')
+    log = tmp_path / 'log.txt'
+    synth.write_text_log(str(log), 1000, 1000, 20)
+    text = _conf_text({'record': str(log), 'recommender': 'FISM', 'num.factors': '10', 'num.max.iter': '2', 'item.ranking': '-topN 5,10',
+                       'learnRate': '-init 0.015 -max 1', 'reg.lambda': '-u 0.01 -i 0.01 -b 0.01 -s 0.01',
+                       'output.setup': 'on -dir ' + str(tmp_path / 'results') + '/'}, {'FISM': '-rho 2 -alpha 0.5'})
+    path = tmp_path / 'fism.conf'
+    path.write_text(text)
+    conf = Config(str(path))
+    rec = FISM(conf, _load(conf), [])
+    rec.readConfiguration()
+    random.seed(int(z['seed']))
+    np.random.seed(int(z['seed']))
+    rec.initModel()
+    assert np.array_equal(rec.P, z['P0']) and np.array_equal(rec.Q, z['Q0']) and np.array_equal(rec.Bi, z['B0'])
+    capsys.readouterr()
+    rec.buildModel()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if 'iteration' in ln]
+    assert lines == meta['lines']
+    assert rel_err(rec.P, z['P']) < 1e-11 and rel_err(rec.Bi, z['Bi']) < 1e-11 and rel_err(rec.Q, z['Q']) < 1e-6
+    assert rec.lRate == float(z['lRate'])
+    rec.evalRanking()
+    assert rec.measure == meta['measure']
+    assert glob.glob(str(tmp_path / 'results' / 'FISM@*items*.txt'))
+    users = list(rec.data.testSet.keys())
+    s = rec.predict(users[3])
+    assert s.dtype == np.float64 and np.abs(s - z['predict16'][3]).max() < 1e-12

@@ -185,9 +185,115 @@ def g7_measure():
               open(os.path.join(OUT, 'g7_measure.json'), 'w'), indent=1)
 
 
+def g8_fism(tmp, logs, datasets):
+    """FISM: recommender/cf/FISM.py runs as it is (NumPy only); ``choice`` is wrapped in
+    its module to log the draws.  Fixtures: initial/final P (f64), Q (f32), Bi (f64), the accepted negatives
+    in processing order, printed lines, predict vectors, evalRanking lists and measures."""
+    import recommender.cf.FISM as fism_mod
+    seed = 20260005
+
+    def conf_for(log_path, k, iters, rho, alpha, topn):
+        out = []
+        for ln in open(os.path.join(REF, 'config/FISM.conf')).read().splitlines():
+            key = ln.split('=')[0]
+            if key == 'record':
+                ln = 'record=' + log_path
+            elif key == 'num.factors':
+                ln = 'num.factors=%d' % k
+            elif key == 'num.max.iter':
+                ln = 'num.max.iter=%d' % iters
+            elif key == 'FISM':
+                ln = 'FISM=-rho %d -alpha %s' % (rho, alpha)
+            elif key == 'item.ranking':
+                ln = 'item.ranking=-topN ' + topn
+            elif key == 'output.setup':
+                ln = 'output.setup=on -dir ' + os.path.join(tmp, 'results_fism') + '/'
+            out.append(ln)
+        path = os.path.join(tmp, 'fism_%d_%d_%d.conf' % (k, iters, rho))
+        open(path, 'w').write('\n'.join(out) + '\n')
+        return path
+
+    def case(tag, log_name, k, iters, rho, alpha, topn='5,10'):
+        conf = Config(conf_for(logs[log_name], k, iters, rho, alpha, topn))
+        rec, _ = quiet(fism_mod.FISM, conf, load_train(conf), [])
+        rec.readConfiguration()
+        random.seed(seed)
+        np.random.seed(seed)
+        rec.initModel()
+        P0, Q0, B0 = rec.P.copy(), rec.Q.copy(), rec.Bi.copy()
+        draws = []
+
+        def logged_choice(seq):
+            x = random.choice(seq)
+            draws.append(x)
+            return x
+        keep = fism_mod.choice
+        fism_mod.choice = logged_choice
+        try:
+            _, out = quiet(rec.buildModel)
+        finally:
+            fism_mod.choice = keep
+        d, rt = rec.data, rec.recType
+        ev_u, ev_i = record_arrays(rec)
+        # accepted negatives in processing order: users with one event are skipped (FISM.py:40-41)
+        listened = defaultdict(set)
+        for user in d.userRecord:
+            for ev in d.userRecord[user]:
+                listened[user].add(ev[rt])
+        it = iter(draws)
+        negs = []
+        for _ep in range(iters):
+            for user in d.userRecord:
+                if len(d.userRecord[user]) == 1:
+                    continue
+                for _ev in d.userRecord[user]:
+                    for _c in range(rho):
+                        j = next(it)
+                        while j in listened[user]:
+                            j = next(it)
+                        negs.append(d.getId(j, rt))
+        assert next(it, None) is None
+        lines = [ln for ln in out.splitlines() if 'iteration' in ln]
+        tu = list(d.testSet.keys())
+        pred = np.stack([rec.predict(u) for u in tu[:16]])
+        captured = {}
+        orig = Measure.rankingMeasure
+
+        def spy(origin, res, N, itemCount):
+            captured['res'] = {u: list(v) for u, v in res.items()}
+            return orig(origin, res, N, itemCount)
+        Measure.rankingMeasure = staticmethod(spy)
+        try:
+            quiet(rec.evalRanking)
+        finally:
+            Measure.rankingMeasure = staticmethod(orig)
+        ids = np.array([[d.getId(x, rt) for x in captured['res'][u]] for u in tu], np.int32)
+        tuid = np.array([d.getId(u, 'user') for u in tu], np.int32)
+        np.savez_compressed(os.path.join(OUT, 'g8_%s.npz' % tag), seed=seed, k=k, iters=iters, rho=rho, alpha=np.float64(alpha),
+                            m=d.getSize('user'), n=Q0.shape[0], ev_u=ev_u, ev_i=ev_i, negs=np.array(negs, np.int32),
+                            draws=np.array([d.getId(x, rt) for x in draws], np.int32),
+                            P0=P0, Q0=Q0, B0=B0, P=rec.P, Q=rec.Q, Bi=rec.Bi, loss=np.float64(rec.loss), lRate=np.float64(rec.lRate),
+                            test_users=tuid, rec_ids=ids, predict16=pred)
+        json.dump({'lines': lines, 'measure': rec.measure, 'dataset': datasets[log_name], 'topN': topn,
+                   'loss_type': type(rec.loss).__name__, 'dtypes': [str(rec.P.dtype), str(rec.Q.dtype), str(rec.Bi.dtype)]},
+                  open(os.path.join(OUT, 'g8_%s.json' % tag), 'w'), indent=1)
+
+    case('fism_c1_k10_e2', 'c1', 10, 2, 2, '0.5')
+    case('fism_d2_k64_e1', 'd2', 64, 1, 1, '0.7')
+    case('fism_d3_k130_e3', 'd3', 130, 3, 3, '0.5', '10,20')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix='yue_gold_')
+    if '--only-fism' in sys.argv:
+        datasets = {'c1': (1000, 1000, 20), 'd2': (200, 300, 20), 'd3': (120, 200, 20)}
+        logs = {}
+        for name, (m, n, d) in datasets.items():
+            logs[name] = os.path.join(tmp, name + '.txt')
+            synth.write_text_log(logs[name], m, n, d)
+        g8_fism(tmp, logs, datasets)
+        return
     g1_config()
     g7_measure()
 
@@ -279,6 +385,8 @@ def main():
     ranking_case('c1_top20', '10,20')
     m6, out6 = quiet(recr.ranking_performance)
     json.dump({'measure': m6, 'stdout': out6}, open(os.path.join(OUT, 'g6_ranking_performance.json'), 'w'), indent=1)
+
+    g8_fism(tmp, logs, datasets)
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden files:', sorted(os.listdir(OUT)), 'total bytes', tot)

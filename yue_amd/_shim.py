@@ -22,7 +22,8 @@ SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy',
            'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
            'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
            'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
-           'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64']
+           'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
+           'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_scores', 'yue_fism_topn_scan']
 
 
 class YueHipError(RuntimeError):
@@ -61,6 +62,11 @@ def _i32(a):
 def _i64(a):
     a = np.ascontiguousarray(a, dtype=np.int64)
     return a, a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
 def comm_unique_id():
@@ -212,6 +218,55 @@ class Device(object):
         return ms.value, nl.value, nt.value
 
     # -- multi-GPU ----------------------------------------------------------------------
+    # -- FISM (parity path) ---------------------------------------------------------------
+    def fism_set_model(self, P, Q, Bi):
+        P, a = _f64(P)
+        Q, b = _f32(Q)
+        Bi, c = _f64(Bi)
+        assert P.shape == Q.shape and len(Bi) == P.shape[0]
+        self.fn, self.fk = P.shape
+        self._chk(self._lib.yue_fism_set_model(self._ctx, a, b, c, C.c_int64(self.fn), C.c_int(self.fk)))
+
+    def fism_get_model(self, P, Q, Bi):
+        """Copies the device model into the given arrays (float64 [n,k], float32 [n,k], float64 [n])."""
+        assert P.dtype == np.float64 and Q.dtype == np.float32 and Bi.dtype == np.float64
+        assert P.flags.c_contiguous and Q.flags.c_contiguous and Bi.flags.c_contiguous
+        self._chk(self._lib.yue_fism_get_model(self._ctx, P.ctypes.data_as(C.POINTER(C.c_double)), Q.ctypes.data_as(C.POINTER(C.c_float)),
+                                               Bi.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def fism_epoch(self, user_ptr, ev_i, negs, rho, coef, lr, regI, regB):
+        """One sequential pass (FISM.py:38-69).  Returns (sum of 0.5*error^2, sum(P*P), sum(Q*Q), Bi.Bi)."""
+        user_ptr, a = _i64(user_ptr)
+        ev_i, b = _i32(ev_i if len(ev_i) else np.zeros(1, np.int32))
+        n_negs = len(negs)
+        negs, c = _i32(negs if n_negs else np.zeros(1, np.int32))
+        coef, d = _f64(coef)
+        half = C.c_double()
+        sums = (C.c_double * 3)()
+        self._chk(self._lib.yue_fism_epoch(self._ctx, a, C.c_int64(len(user_ptr) - 1), b, c, C.c_int64(n_negs), C.c_int(rho), d,
+                                           C.c_double(lr), C.c_double(regI), C.c_double(regB), C.byref(half), sums))
+        return half.value, sums[0], sums[1], sums[2]
+
+    def fism_scores(self, items):
+        items, a = _i32(items if len(items) else np.zeros(1, np.int32))
+        out = np.empty(self.fn, np.float64)
+        self._chk(self._lib.yue_fism_scores(self._ctx, a, C.c_int64(len(items)), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def fism_topn_scan(self, row_ptr, row_items, N):
+        """(ids[nu,N] int32, scores[nu,N] float64) for users given by the CSR of their training events."""
+        row_ptr, a = _i64(row_ptr)
+        nu = len(row_ptr) - 1
+        row_items, b = _i32(row_items if len(row_items) else np.zeros(1, np.int32))
+        ids = np.empty((nu, N), np.int32)
+        sc = np.empty((nu, N), np.float64)
+        rc = self._lib.yue_fism_topn_scan(self._ctx, a, b, C.c_int64(nu), C.c_int(N), ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          sc.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc == ERR_FEW_ITEMS:
+            raise IndexError(self._lib.yue_last_error().decode())
+        self._chk(rc)
+        return ids, sc
+
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._chk(self._lib.yue_comm_init(self._ctx, buf, C.c_int(rank), C.c_int(nranks)))

@@ -1,0 +1,212 @@
+// FISM (recommender/cf/FISM.py of the reference) on gfx950 -- the parity path.
+//
+// The reference's loop is strictly sequential: every draw of every event of every user rewrites
+// Q[i], Q[j], Bi[i], Bi[j] in place, the next draw reads them, and the user's item-history rows P[.]
+// are rewritten when the user is done (FISM.py:38-69).  Users share items, so the dependency chain runs
+// through the whole epoch: k_fism_epoch is ONE wave that walks the epoch in the reference's order
+// (lane l holds elements 64r + l of a row).  It exists to reproduce the reference, not to be fast; a
+// round-based throughput version (as k_round is for BPR) is the next step for this model.
+//
+// Types as the reference leaves them: P float64 [n,k] (item-history factors), Q float32 [n,k],
+// Bi float64 [n].  Arithmetic follows the NumPy expressions term by term (python-float coefficients,
+// float32 products where NumPy forms them in float32, float64 sums rounded into the float32 rows);
+// the file is compiled with -ffp-contract=off.  The k-length dots are 64 strided partials + a
+// butterfly in double (the reference's BLAS ddot order is not pinned: results agree to ~1e-15 rel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace yue {
+
+struct FismArgs {
+    double *P;                   // [n,k]
+    float *Q;                    // [n,k]
+    double *Bi;                  // [n]
+    int64_t n;
+    int k;
+    const int64_t *user_ptr;     // [m+1] events of user u are ev_i[user_ptr[u] : user_ptr[u+1]]
+    int64_t m;
+    const int32_t *ev_i;
+    const int32_t *negs;         // accepted negatives in processing order, rho per event of users with > 1 event
+    int rho;
+    const double *coef;          // [m] pow(nu - 1, -alpha), formed on the host as Python forms it (FISM.py:42)
+    double lr, regI, regB;
+    double *x_rows;              // scratch [max events of one user][k]
+    double *out;                 // out[0] = sum of 0.5 * error^2
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+
+// Loads / stores that go to L2 (sc1): the wave re-reads rows it has just rewritten, the L1 must not
+// serve them.
+__device__ __forceinline__ double ldg_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldg_f32(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stg_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stg_f32(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int KR>
+__global__ void __launch_bounds__(64) k_fism_epoch(FismArgs a) {
+    const int lane = threadIdx.x;
+    const int k = a.k;
+    const float regI32 = (float)a.regI;                  // `regI * Q[i]`: python float times a float32 row stays float32
+    double half_sq = 0.0;
+    int64_t cursor = 0;
+    for (int64_t u = 0; u < a.m; ++u) {
+        const int64_t e0 = a.user_ptr[u], e1 = a.user_ptr[u + 1];
+        const int64_t nu = e1 - e0;
+        if (nu <= 1) continue;                           // FISM.py:40-41 (a user without events has nothing to do either)
+        const double coef = a.coef[u];
+        double hist[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) hist[r] = 0.0;
+        for (int64_t e = e0; e < e1; ++e) {              // :44-46
+            const int64_t it = a.ev_i[e];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) hist[r] = hist[r] + ldg_f64(a.P + it * k + el); }
+        }
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t i = a.ev_i[e];
+            double x[KR];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) x[r] = 0.0;
+            for (int c = 0; c < a.rho; ++c) {
+                const int64_t j = a.negs[cursor++];
+                double di[KR], dj[KR];
+                float qi[KR], qj[KR];
+                double ai = 0.0, aj = 0.0;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int el = 64 * r + lane;
+                    di[r] = dj[r] = 0.0; qi[r] = qj[r] = 0.0f;
+                    if (el < k) {
+                        di[r] = hist[r] - ldg_f64(a.P + i * k + el);
+                        dj[r] = hist[r] - ldg_f64(a.P + j * k + el);
+                        qi[r] = ldg_f32(a.Q + i * k + el);
+                        qj[r] = ldg_f32(a.Q + j * k + el);
+                    }
+                    const double m1 = di[r] * (double)qi[r]; ai = ai + m1;
+                    const double m2 = dj[r] * (double)qj[r]; aj = aj + m2;
+                }
+                const double bi = ldg_f64(a.Bi + i), bj = ldg_f64(a.Bi + j);
+                const double r_pos = coef * wave_sum_f64(ai) + bi;          // :54
+                const double r_neg = coef * wave_sum_f64(aj) + bj;          // :55
+                const double err = 1.0 - (r_pos - r_neg);
+                half_sq = half_sq + 0.5 * (err * err);                      // :58
+                if (lane == 0) {
+                    stg_f64(a.Bi + i, bi + a.lr * (err - a.regB * bi));     // :59
+                    stg_f64(a.Bi + j, bj - a.lr * (err + a.regB * bj));     // :60
+                }
+                const double ec = err * coef;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int el = 64 * r + lane;
+                    const float ri = regI32 * qi[r], rj = regI32 * qj[r];
+                    const float ni = (float)((double)qi[r] + a.lr * (ec * di[r] - (double)ri));     // :61
+                    const float nj = (float)((double)qj[r] - a.lr * (ec * dj[r] + (double)rj));     // :62
+                    const float dq = ni - nj;
+                    x[r] = x[r] + err * (double)dq;                                                  // :63
+                    if (el < k) { stg_f32(a.Q + i * k + el, ni); stg_f32(a.Q + j * k + el, nj); }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) stg_f64(a.x_rows + (e - e0) * k + el, x[r]); }
+        }
+        const double pc = 1.0 / (double)a.rho * coef;                       // :68, left to right
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t it = a.ev_i[e];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int el = 64 * r + lane;
+                if (el < k) {
+                    const double p = ldg_f64(a.P + it * k + el);
+                    stg_f64(a.P + it * k + el, p + a.lr * (pc * ldg_f64(a.x_rows + (e - e0) * k + el) - a.regI * p));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (lane == 0) a.out[0] = half_sq;
+}
+
+// FISM.py:70: sum(P*P), sum(Q*Q) (float32 products), Bi.Bi -- accumulated in double.
+__global__ void __launch_bounds__(256) k_fism_sumsq(const double *P, const float *Q, const double *Bi, int64_t n, int k, double *out3) {
+    __shared__ double part[3][4];
+    double sp = 0.0, sq = 0.0, sb = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tot = n * k;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const double p2 = P[t] * P[t]; sp += p2;
+        const float q2 = Q[t] * Q[t]; sq += (double)q2;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) { const double b2 = Bi[t] * Bi[t]; sb += b2; }
+    for (int off = 32; off >= 1; off >>= 1) { sp += __shfl_xor(sp, off); sq += __shfl_xor(sq, off); sb += __shfl_xor(sb, off); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = sp; part[1][threadIdx.x >> 6] = sq; part[2][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(out3 + threadIdx.x, part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
+}
+
+// predict (FISM.py:75-83): hist[t] = sum of P rows of the listed user's training events (one block per user) ...
+__global__ void __launch_bounds__(256) k_fism_hist(const double *P, int k, const int64_t *row_ptr, const int32_t *row_items, double *hist) {
+    const int64_t t = blockIdx.x;
+    for (int el = threadIdx.x; el < k; el += 256) {
+        double s = 0.0;
+        for (int64_t e = row_ptr[t]; e < row_ptr[t + 1]; ++e) s = s + P[(int64_t)row_items[e] * k + el];
+        hist[t * k + el] = s;
+    }
+}
+
+// ... scores[t][it] = Bi[it] + Q[it].hist[t] - sum_e P[it][e] * Q[it][e], element order ascending.
+__global__ void __launch_bounds__(256) k_fism_scores(const double *P, const float *Q, const double *Bi, int64_t n, int k,
+                                                     const double *hist, int64_t nu, double *scores) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nu * n) return;
+    const int64_t t = idx / n, it = idx - t * n;
+    const double *h = hist + t * k, *p = P + it * k;
+    const float *q = Q + it * k;
+    double d = 0.0, s = 0.0;
+    for (int e = 0; e < k; ++e) {
+        const double qe = (double)q[e];
+        const double m1 = qe * h[e]; d = d + m1;
+        const double m2 = p[e] * qe; s = s + m2;
+    }
+    scores[idx] = Bi[it] + d - s;
+}
+
+// The reference's selection (base/IterativeRecommender.py:98-145) on explicit float64 score rows: one
+// thread per listed user, candidates = item ids ascending minus the user's training items (row_items,
+// unsorted, duplicates allowed).  out_ids[t][N], out_scores[t][N]; flags[t] = 1 if fewer than N candidates.
+__global__ void __launch_bounds__(64) k_fism_select(const double *scores, int64_t n, int64_t nu, int N,
+                                                    const int64_t *row_ptr, const int32_t *row_items,
+                                                    int32_t *out_ids, double *out_scores, int32_t *flags) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= nu) return;
+    const double *sc = scores + t * n;
+    double *a = out_scores + t * N;
+    int32_t *id = out_ids + t * N;
+    const int64_t m0 = row_ptr[t], m1 = row_ptr[t + 1];
+    auto masked = [&](int64_t it) { for (int64_t e = m0; e < m1; ++e) if (row_items[e] == it) return true; return false; };
+    int cnt = 0;
+    for (int64_t it = 0; it < n && cnt < N; ++it) {
+        if (masked(it)) continue;
+        int pos = cnt;                                   // stable insertion == list.sort(reverse=True) on the seed
+        while (pos > 0 && a[pos - 1] < sc[it]) { a[pos] = a[pos - 1]; id[pos] = id[pos - 1]; --pos; }
+        a[pos] = sc[it]; id[pos] = (int32_t)it; ++cnt;
+    }
+    flags[t] = cnt < N;
+    if (cnt < N) { for (int q = cnt; q < N; ++q) { a[q] = -INFINITY; id[q] = -1; } return; }
+    for (int64_t it = 0; it < n; ++it) {
+        if (masked(it)) continue;
+        const double s = sc[it];
+        if (a[N - 1] < s) {
+            int p = 0;
+            while (a[p] >= s) ++p;                       // first slot strictly below s
+            a[p] = s; id[p] = (int32_t)it;
+        }
+    }
+}
+
+}  // namespace yue
