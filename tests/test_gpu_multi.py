@@ -28,3 +28,17 @@ def test_communicator_epoch_matches_sharded_spec(orc):
         assert rel_err(Pg, P) < 1e-5 and rel_err(Qg, Q) < 1e-5
         assert abs(nll - nll_s) <= 1e-9 * abs(nll_s)
     dev.close()
+
+
+def test_library_works_after_torch_was_loaded():
+    # bench.py --gpus N imports torch.distributed (gloo control plane) before the library; the ROCm build of
+    # torch brings its own libamdhip64 / librccl, which the library then binds to.  Fresh interpreter.
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_torch_coexistence.py')], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600, env=env)
+    out = res.stdout.decode()
+    assert res.returncode == 0 and out.strip().endswith('ok'), out[-2000:]
