@@ -32,6 +32,9 @@ WORKLOADS = {
     'c3': (1000000, 200000, 50, 128),
     'c2': (100000, 50000, 50, 64),
     'tiny': (20000, 5000, 20, 128),
+    # one GPU's share of BASELINE config 4 (10M users x 1M items over 8 GPUs): replicated 5.1 GB of user factors,
+    # a 125K-item shard, 60M of the 500M events; run with --force-comm to take the all-reduce path on one rank
+    'c4shard': (10000000, 125000, 6, 128),
     # scoring (BASELINE config 5): all users x all items, top-20 selection, training items masked
     'c5': (1000000, 200000, 50, 128),
     'c5small': (65536, 200000, 50, 128),
