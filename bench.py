@@ -251,7 +251,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
-    ap.add_argument('--round-events', type=int, default=32768)
+    ap.add_argument('--round-events', type=int, default=0, help='events per S-round; 0 = the library\'s default for this device (one resident wave set)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--scan-f32', action='store_true', help='scoring workloads: force the exact f32-MFMA kernel')
     ap.add_argument('--tpw', type=int, default=0, help='tuning: events per wave in the round kernel (0 = default)')
@@ -290,6 +290,8 @@ def main():
     if args.force_comm and world == 1:
         from yue_amd._shim import comm_unique_id
         dev.comm_init(comm_unique_id(), 0, 1)
+    if args.round_events <= 0:
+        args.round_events = dev.default_round_events()
     setup_s = time.perf_counter() - t_setup
 
     seed = 20260003
@@ -329,7 +331,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: BPR k=%d, %d users x %d items per GPU, %d events/user (%d triplets per epoch per GPU), '
-                                   'counter-based sampler (one pass per epoch, inside the timed step), S-round W=%d events, lr=%g regU=regI=%g'
+                                   'counter-based sampler (one pass per epoch, inside the timed step), S-round W=%d events (the device default unless --round-events is given), lr=%g regU=regI=%g'
                                    % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),
                        'round_events': args.round_events, 'parallelism': 'items sharded x%d, users replicated' % world,
                        'setup_s': round(setup_s, 1), 'final_nll_per_triplet': nll / E},

@@ -78,7 +78,8 @@ int yue_bpr_rounds(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32
 
 /*
  * One epoch over the uploaded events; negatives from the device's counter-based sampler.
- * Rounds are round_events consecutive events (on a communicator: user-aligned blocks of about
+ * Rounds are round_events consecutive events; 0 = the device's default, yue_default_round_events (on a
+ * communicator: user-aligned blocks of about
  * that many events, identical user ranges on every rank, user-factor gradients all-reduced).
  * Outputs: nll (sum of -log s over this rank's triplets), sums of squares of P and of this
  * rank's Q after the epoch (for BPR.py:59).  Any output pointer may be NULL.
@@ -86,6 +87,11 @@ int yue_bpr_rounds(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32
 int yue_bpr_epoch(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int64_t round_events,
                   double lr, double regU, double regI,
                   double *nll_out, double *sumsqP_out, double *sumsqQ_out);
+
+/* The default round size for the uploaded k on this device: the events one resident set of waves of the round
+ * kernel takes (a launch is then a single wave generation); 43,008 on MI355X at k = 128.  Results depend on the
+ * round size: pass an explicit value where runs must be comparable across devices. */
+int yue_default_round_events(yue_ctx *ctx, int64_t *out);
 
 /* Negatives the device sampler draws for (seed, epoch): j_out[E], -1 where all attempts were rejected. */
 int yue_sample_negatives(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int32_t *j_out);

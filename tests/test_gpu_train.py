@@ -213,6 +213,31 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (sampler, stage)
 
 
+def test_default_round_size_is_one_resident_wave_set(orc):
+    # round_events = 0 -> yue_default_round_events: a multiple of 1024 that fits the chip's resident workgroups
+    # (update workgroups of 32 events + count blocks of 256 events); the epoch equals the explicit call
+    from yue_amd._shim import Device
+    m, n, d, k = 3000, 2000, 20, 128
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=11)
+    out = []
+    for explicit in (False, True):
+        dev = Device(0, raise_errors=True)
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        W = dev.default_round_events()
+        assert W % 1024 == 0 and 8192 <= W <= 131072
+        nll, _, _ = dev.bpr_epoch(3, 0, W if explicit else 0, 0.02, 0.01, 0.01)
+        out.append((nll,) + dev.get_factors())
+        dev.close()
+    assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(out[1][0]) and rel_err(out[0][1], out[1][1]) < TOL and rel_err(out[0][2], out[1][2]) < TOL
+    E = len(ev_u)
+    j = orc.sample_counter(3, 0, ev_u, n, data['indptr'], data['indices'])
+    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+    assert rel_err(out[0][1], Po) < TOL and rel_err(out[0][2], Qo) < TOL and abs(out[0][0] - nll_o) <= 1e-9 * abs(nll_o)
+
+
 def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):
     # user 0 listened to all but one item (sampler mostly rejects), user 1 has no events at all
     m, n, k = 3, 40, 16

@@ -23,6 +23,7 @@ SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy',
            'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
            'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
+           'yue_default_round_events',
            'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_scores', 'yue_fism_topn_scan']
 
 
@@ -157,6 +158,11 @@ class Device(object):
         nll = C.c_double()
         self._chk(self._lib.yue_bpr_rounds(self._ctx, a, b, c, d, C.c_int64(len(rp) - 1), C.c_double(lr), C.c_double(regU), C.c_double(regI), C.byref(nll)))
         return nll.value
+
+    def default_round_events(self):
+        out = C.c_int64()
+        self._chk(self._lib.yue_default_round_events(self._ctx, C.byref(out)))
+        return out.value
 
     def bpr_epoch(self, seed, epoch, round_events, lr, regU, regI):
         """Returns (nll, sumsqP, sumsqQ) after one fused-sampler epoch."""

@@ -146,6 +146,33 @@ int tpw_of(const yue_ctx *c) {
     return kr_of(c->k) == 4 ? 4 : 8;      // measured on C3 (k=128): 8 events per wave 53.9 ms/epoch, 4 -> 58.7 ms
 }
 
+// Default round size: as many events as ONE resident set of waves of the round kernel takes (update
+// workgroups of 4 waves x TPW events plus the next round's count blocks of 256 events), so that a launch
+// is a single wave generation -- measured optimum on MI355X (43,008 at k = 128).
+int default_round_events(yue_ctx *c, int64_t *out) {
+    const int tpw = tpw_of(c);
+    int per_cu = 0, cus = 0;
+    hipError_t e = hipSuccess;
+    switch (kr_of(c->k) * 16 + tpw) {
+        case 1 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 8>, 256, 0); break;
+        case 2 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 8>, 256, 0); break;
+        case 4 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<4, 4>, 256, 0); break;
+        case 1 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 4>, 256, 0); break;
+        case 2 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 4>, 256, 0); break;
+        case 1 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 2>, 256, 0); break;
+        case 2 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 2>, 256, 0); break;
+        default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
+    }
+    HIPCHK(e);
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const double slots = (double)per_cu * (double)cus;                    // resident workgroups of 256 threads
+    const double per_event = 1.0 / (4.0 * tpw) + 1.0 / 256.0;             // workgroups one event needs (update + count)
+    int64_t w = (int64_t)(slots / per_event);
+    w -= w % 1024;
+    *out = std::max<int64_t>(w, 1024);
+    return YUE_OK;
+}
+
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
 // Every timing_stride-th launch is bracketed with HIP events on the library's stream.
 int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
@@ -519,8 +546,9 @@ int yue_sumsq(yue_ctx *c, double *sp, double *sq) {
 int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_events, double lr, double regU, double regI,
                   double *nll_out, double *sumsqP_out, double *sumsqQ_out) {
     if (!c || !c->have_factors || !c->have_inter) return fail(YUE_ERR_ARG, "yue_bpr_epoch: upload factors and interactions first");
-    if (round_events <= 0) return fail(YUE_ERR_ARG, "yue_bpr_epoch: round_events must be positive");
+    if (round_events < 0) return fail(YUE_ERR_ARG, "yue_bpr_epoch: round_events must be positive (or 0 for the device's default)");
     HIPCHK(hipSetDevice(c->device));
+    if (round_events == 0) { const int rc0 = default_round_events(c, &round_events); if (rc0) return rc0; }
     yue::TrainArgs a = make_args(c, lr, regU, regI);
     a.seed = seed + 0x632BE59BD9B4E019ull * (uint64_t)c->rank;   // independent stream per item shard
     a.epoch = epoch;
@@ -571,6 +599,12 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
     return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
+}
+
+int yue_default_round_events(yue_ctx *c, int64_t *out) {
+    if (!c || !c->have_factors || !out) return fail(YUE_ERR_ARG, "yue_default_round_events: upload factors first (the value depends on k)");
+    HIPCHK(hipSetDevice(c->device));
+    return default_round_events(c, out);
 }
 
 int yue_set_kernel_timing(yue_ctx *c, int stride) {

@@ -9,9 +9,10 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
                                         BPR.py:46-48, so a seeded `random` gives the same stream);
                                         the device applies the triplets with exact sequential
                                         semantics (yue_bpr_replay).  Same results as the reference.
-  bpr.hip=-mode epoch -round 32768 -seed 1
-                                        throughput mode: counter-based sampler fused into the
-                                        update kernel, S-round semantics.
+  bpr.hip=-mode epoch -round auto -seed 1
+                                        throughput mode: counter-based sampler on the device,
+                                        S-round semantics; -round N fixes the round size
+                                        (auto = the device's default, 43,008 events on MI355X at k=128).
   -gpu N                                HIP device ordinal.
   -topn true                            evalRanking returns a real top-N (descending, ties: lower item id)
                                         instead of the reference's order-dependent overwrite-scan.
@@ -37,7 +38,7 @@ class BPR(IterativeRecommender):
         self.train_size = len(self.data.trainingData)
 
     def _options(self):
-        opts = {'-mode': 'replay', '-round': '32768', '-seed': '1'}
+        opts = {'-mode': 'replay', '-round': 'auto', '-seed': '1'}
         if self.config.contains('bpr.hip'):
             given = LineConfig(self.config['bpr.hip'])
             for key in opts:
@@ -77,7 +78,7 @@ class BPR(IterativeRecommender):
                 nll = dev.bpr_replay(ev_u, arr['ev_i'], j, self.lRate, self.regU, self.regI)
                 sumP, sumQ = dev.sumsq()
             else:
-                nll, sumP, sumQ = dev.bpr_epoch(int(opts['-seed']), iteration, int(opts['-round']), self.lRate, self.regU, self.regI)
+                nll, sumP, sumQ = dev.bpr_epoch(int(opts['-seed']), iteration, 0 if opts['-round'] == 'auto' else int(opts['-round']), self.lRate, self.regU, self.regI)
             # BPR.py:58-59.  Under NumPy 2 `regU * (P*P).sum()` is a float32 and turns the loss into
             # a float32; the same promotion is applied here so the printed line matches.
             self.loss = nll + (self.regU * np.float32(sumP) + self.regI * np.float32(sumQ))
