@@ -335,7 +335,7 @@ def main():
                                    % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),
                        'round_events': args.round_events, 'parallelism': 'items sharded x%d, users replicated' % world,
                        'setup_s': round(setup_s, 1), 'final_nll_per_triplet': nll / E},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + next-round touch-count blocks)' % (1 if k <= 64 else 2 if k <= 128 else 4),
+            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + touch tickets of the next round)' % (1 if k <= 64 else 2 if k <= 128 else 4),
                          'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                          'algorithmic_bytes_per_triplet': ab, 'launches_timed': k_launches,
                          'avg_launch_ms': (k_ms / k_launches) if k_launches else None,

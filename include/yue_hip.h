@@ -89,7 +89,7 @@ int yue_bpr_epoch(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int64_t round_eve
                   double *nll_out, double *sumsqP_out, double *sumsqQ_out);
 
 /* The default round size for the uploaded k on this device: the events one resident set of waves of the round
- * kernel takes (a launch is then a single wave generation); 43,008 on MI355X at k = 128.  Results depend on the
+ * kernel takes (a launch is then a single wave generation); 49,152 on MI355X at k = 128.  Results depend on the
  * round size: pass an explicit value where runs must be comparable across devices. */
 int yue_default_round_events(yue_ctx *ctx, int64_t *out);
 
@@ -124,8 +124,6 @@ int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t
 /* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
  *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8
- *   "epoch_sampler" 0 (default): yue_bpr_epoch draws the epoch's negatives in one pass up front;
- *               1: the round launches draw the next round's negatives themselves (same negatives)
  *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in
  *               staging rows (write-through stores, summed in event order by the last toucher);
  *               0: every contended row goes through float atomics

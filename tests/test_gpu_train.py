@@ -191,8 +191,8 @@ def test_round_kernel_under_heavy_contention_and_many_wave_passes(orc, tpw):
 
 
 def test_tuning_knobs_do_not_change_the_epoch(orc):
-    # epoch_sampler: the same negatives either way -> identical factors up to the order of atomic sums;
-    # round_stage: staging rows vs float atomics for rows with 2..4 touches -> same sums, another fp32 order
+    # round_stage: staging rows vs float atomics for rows with 2..4 touches -> same sums, another fp32 order;
+    # round_tpw: events per wave
     from yue_amd._shim import Device
     m, n, d, k, W = 4000, 2500, 25, 128, 8192
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=21)
@@ -201,21 +201,21 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
     rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
     j = orc.sample_counter(9, 0, ev_u, n, data['indptr'], data['indices'])
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
-    for sampler, stage in [(0, 1), (1, 1), (0, 0), (1, 0)]:
+    for tpw, stage in [(0, 1), (0, 0), (4, 1), (2, 0)]:
         dev = Device(0, raise_errors=True)
-        dev.set_option('epoch_sampler', sampler)
+        dev.set_option('round_tpw', tpw)
         dev.set_option('round_stage', stage)
         dev.set_factors(P0, Q0)
         dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
         nll, _, _ = dev.bpr_epoch(9, 0, W, 0.02, 0.01, 0.01)
         P, Q = dev.get_factors()
         dev.close()
-        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (sampler, stage)
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (tpw, stage)
 
 
 def test_default_round_size_is_one_resident_wave_set(orc):
     # round_events = 0 -> yue_default_round_events: a multiple of 1024 that fits the chip's resident workgroups
-    # (update workgroups of 32 events + count blocks of 256 events); the epoch equals the explicit call
+    # (32 events each at 8 events per wave); the epoch equals the explicit call
     from yue_amd._shim import Device
     m, n, d, k = 3000, 2000, 20, 128
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=11)

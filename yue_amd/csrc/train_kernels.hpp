@@ -22,8 +22,7 @@ struct TrainArgs {
     float *P, *Q, *dP, *dQ;
     float *stage;                // staged item-row differences of the running round: one k-float row per touch
 #ifdef YUE_STAMPS
-    unsigned long long *stamps;  // diagnostic build only (make stamps): 8 phase time stamps per update wave, then per prep block
-    long long stamp_waves;
+    unsigned long long *stamps;  // diagnostic build only (make stamps): 8 phase time stamps per update wave
 #endif
     const int32_t *ev_u, *ev_i;
     int32_t *ev_j;
@@ -55,8 +54,6 @@ struct RoundArgs {
     uint32_t *tab_cur, *tab_next;
     int staged;                  // 1: rows with 2..kStageMax touches go through the staging rows instead of float atomics
     int apply_p;                 // 1: user rows are finished in this launch; 0: dP is left for the all-reduce
-    int sample_next;             // 1: draw ev_j for the next round (fused sampler); 0: ev_j is given
-    int prep_blocks;             // blocks [0, prep_blocks) run the sample+count role
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -186,10 +183,10 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 }
 
 // ------------------------------------------------------------------------------------------
-// S-round launch.  Blocks [0, prep_blocks) prepare the NEXT round (one thread per event: take a
-// ticket on the two item rows = touch count + staging-slot table, count the user-row flushes; with
-// sample_next also draw the negative -- yue_bpr_epoch draws an epoch's negatives up front with
-// k_sample instead).  The other blocks update THIS round: one wave takes
+// S-round launch.  Every wave first takes the tickets of TPW events of the NEXT round (touch count +
+// staging-slot table of their two item rows, user-row flush counts; lanes TPW .. 2 TPW - 1), then
+// updates TPW events of THIS round -- no separate workgroups for the counting, so every resident
+// workgroup carries 4 * TPW events of the round (the negatives come from k_sample, drawn up front): one wave takes
 // TPW consecutive events, requests all their rows up front (straight-line code: the compiler's
 // counted waits keep every gather in flight), evaluates the TPW sigmoids in one double-precision
 // pass (lane t holds triplet t), then writes:
@@ -228,45 +225,39 @@ constexpr unsigned kStageMax = 4;                          // touches per row se
 
 // evu / evi / evj: the event arrays again, as restrict-qualified read-only views of THIS round's
 // range, so that the wave-uniform reads of a batch's (u, i, j) become scalar loads (s_load): they do
-// not queue behind the vector-memory traffic of the other waves.  (The prep role writes ev_j of the
-// NEXT round's range through a.ev_j -- a disjoint range.)
+// not queue behind the vector-memory traffic of the other waves.
 template <int KR, int TPW>
 __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const int32_t *__restrict__ evu,
                                                const int32_t *__restrict__ evi, const int32_t *__restrict__ evj) {
     const int lane = threadIdx.x & 63;
-    if ((int)blockIdx.x < ra.prep_blocks) {
-#ifdef YUE_STAMPS
-        if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8] = wall_clock64();
-#endif
-        const int64_t e = ra.n_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
-        if (e < ra.n_end) {
-            const int32_t i = a.ev_i[e];
-            int32_t j;
-            if (ra.sample_next) { j = sample_negative(a, a.ev_u[e], e); a.ev_j[e] = j; }
-            else j = a.ev_j[e];
-            if (j >= 0) {
-                // the low half before the add is this touch's ticket on its row
-                const uint32_t ti = (uint32_t)atomicAdd(ra.cnt_next + i, kTouch), tj = (uint32_t)atomicAdd(ra.cnt_next + j, kTouch);
-                if (ra.staged) {
-                    const uint32_t slot = 2u * (uint32_t)(e - ra.n_begin);
-                    if (ti < kStageMax) ra.tab_next[(size_t)i * kStageMax + ti] = slot;
-                    if (tj < kStageMax) ra.tab_next[(size_t)j * kStageMax + tj] = slot + 1u;
-                }
-            }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Tickets of the NEXT round: lanes TPW .. 2 TPW - 1 of wave w take them for events n_begin + w * TPW + (lane - TPW)
+    // -- one returning atomic per item row (the low half before the add is the touch's ticket on its row), one
+    // flush count per run of equal users.  An updating wave issues them behind its row stores, so that they
+    // return inside the drain wait it needs anyway (in front of the gathers they would hold the gathers back:
+    // returns are in order and atomics are the slowest); the slot-table entries follow the wait.
+    uint32_t tk_i = 0xffffffffu, tk_j = 0xffffffffu, nx_slot = 0u;
+    int32_t nx_i = 0, nx_j = -1;
+    auto take_tickets = [&]() {
+        const int64_t ne = ra.n_begin + wave * TPW + (lane - TPW);
+        if (lane >= TPW && lane < 2 * TPW && ne < ra.n_end) {
+            nx_i = a.ev_i[ne]; nx_j = a.ev_j[ne];
+            nx_slot = 2u * (uint32_t)(ne - ra.n_begin);
+            if (nx_j >= 0) { tk_i = (uint32_t)atomicAdd(ra.cnt_next + nx_i, kTouch); tk_j = (uint32_t)atomicAdd(ra.cnt_next + nx_j, kTouch); }
             if (ra.apply_p) {      // one flush per run of equal users inside a TPW-aligned batch
-                const int32_t u = a.ev_u[e];
-                if ((e - ra.n_begin) % TPW == 0 || a.ev_u[e - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
+                const int32_t u = a.ev_u[ne];
+                if (lane == TPW || a.ev_u[ne - 1] != u) atomicAdd(ra.cntp_next + u, 1u);
             }
         }
-#ifdef YUE_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)a.stamp_waves + blockIdx.x) * 8 + 7] = wall_clock64();
-#endif
-        return;
-    }
-    const int64_t wave = (int64_t)(blockIdx.x - ra.prep_blocks) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    };
+    auto publish_slots = [&]() {
+        if (ra.staged && nx_j >= 0) {
+            if (tk_i < kStageMax) ra.tab_next[(size_t)nx_i * kStageMax + tk_i] = nx_slot;
+            if (tk_j < kStageMax) ra.tab_next[(size_t)nx_j * kStageMax + tk_j] = nx_slot + 1u;
+        }
+    };
     const int64_t base = ra.e_begin + wave * TPW;
-    if (base >= ra.e_end) return;
+    if (base >= ra.e_end) { take_tickets(); publish_slots(); return; }
     YUE_STAMP(0, "");
 
     // batch header through the scalar unit: (u, i, j) of the TPW events
@@ -413,8 +404,10 @@ __global__ void __launch_bounds__(256) k_round(TrainArgs a, RoundArgs ra, const 
             sj[0] = wj.x; sj[1] = wj.y; sj[2] = wj.z; sj[3] = wj.w;
         }
     }
+    take_tickets();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YUE_STAMP(5, "");
+    publish_slots();
     // entries beyond the row's touch count are leftovers of earlier rounds: drop them, then put the
     // slots in ascending order = event order, the order in which the oracle sums a row's differences
     static_assert(kStageMax == 4, "the sorting network below is written for four slots");

@@ -70,7 +70,7 @@ struct yue_ctx {
     bool staged = false;                         // the running call uses the staging rows
 #ifdef YUE_STAMPS
     DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
-    int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0, stamp_prep = 0;
+    int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0;
 #endif
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
@@ -89,7 +89,6 @@ struct yue_ctx {
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
-    int opt_epoch_sampler = 0;           // 0: negatives of an epoch drawn by one pass up front; 1: by the round launches (fused)
     // kernel timing
     int timing_stride = 0;
     int64_t launch_counter = 0;
@@ -146,9 +145,9 @@ int tpw_of(const yue_ctx *c) {
     return kr_of(c->k) == 4 ? 4 : 8;      // measured on C3 (k=128): 8 events per wave 53.9 ms/epoch, 4 -> 58.7 ms
 }
 
-// Default round size: as many events as ONE resident set of waves of the round kernel takes (update
-// workgroups of 4 waves x TPW events plus the next round's count blocks of 256 events), so that a launch
-// is a single wave generation -- measured optimum on MI355X (43,008 at k = 128).
+// Default round size: as many events as ONE resident set of waves of the round kernel takes (workgroups of
+// 4 waves x TPW events), so that a launch is a single wave generation -- the measured optimum on MI355X
+// (49,152 at k = 128).
 int default_round_events(yue_ctx *c, int64_t *out) {
     const int tpw = tpw_of(c);
     int per_cu = 0, cus = 0;
@@ -166,8 +165,7 @@ int default_round_events(yue_ctx *c, int64_t *out) {
     HIPCHK(e);
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     const double slots = (double)per_cu * (double)cus;                    // resident workgroups of 256 threads
-    const double per_event = 1.0 / (4.0 * tpw) + 1.0 / 256.0;             // workgroups one event needs (update + count)
-    int64_t w = (int64_t)(slots / per_event);
+    int64_t w = (int64_t)(slots * 4.0 * tpw);
     w -= w % 1024;
     *out = std::max<int64_t>(w, 1024);
     return YUE_OK;
@@ -176,7 +174,7 @@ int default_round_events(yue_ctx *c, int64_t *out) {
 // One S-round launch: update [e0,e1) with the counts in cnt_cur, prepare [n0,n1) into cnt_next.
 // Every timing_stride-th launch is bracketed with HIP events on the library's stream.
 int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t n0, int64_t n1,
-                 int parity, int sample_next, int apply_p) {
+                 int parity, int apply_p) {
     unsigned long long *cnt[2] = {c->cnt0.p, c->cnt1.p};
     uint32_t *cntp[2] = {c->cntp0.p, c->cntp1.p};
     yue::RoundArgs ra{};
@@ -184,11 +182,10 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     ra.cnt_cur = cnt[parity]; ra.cnt_next = cnt[parity ^ 1]; ra.cntp_cur = cntp[parity]; ra.cntp_next = cntp[parity ^ 1];
     uint32_t *tab[2] = {c->tab0.p, c->tab1.p};
     ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1]; ra.staged = c->staged ? 1 : 0;
-    ra.sample_next = sample_next; ra.apply_p = apply_p;
-    ra.prep_blocks = (int)((n1 - n0 + 255) / 256);
+    ra.apply_p = apply_p;
     const int tpw = tpw_of(c);
-    const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
-    const int64_t blocks = ra.prep_blocks + (waves + 3) / 4;
+    const int64_t waves = (std::max(e1 - e0, n1 - n0) + tpw - 1) / tpw;      // every wave: tickets of the next round + its update batch
+    const int64_t blocks = (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
     const bool timed = e1 > e0 && c->timing_stride > 0 && (c->launch_counter++ % c->timing_stride) == 0;
     if (timed) {
@@ -206,12 +203,10 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     yue::TrainArgs a = a_in;
     a.stamps = nullptr;
     if (e1 > e0 && c->update_launches++ == c->stamp_launch) {
-        HIPCHK(c->stamps.resize((size_t)(waves + ra.prep_blocks) * 8));
-        HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)(waves + ra.prep_blocks) * 64, c->stream));
+        HIPCHK(c->stamps.resize((size_t)waves * 8));
+        HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)waves * 64, c->stream));
         a.stamps = c->stamps.p;
-        a.stamp_waves = waves;
-        c->stamp_waves = waves;
-        c->stamp_prep = ra.prep_blocks;
+        c->stamp_waves = (e1 - e0 + tpw - 1) / tpw;
     }
 #else
     const yue::TrainArgs &a = a_in;
@@ -237,7 +232,7 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 // Runs the non-empty rounds bounds[r]..bounds[r+1] in order.  after_round(r) is called once the
 // launches of round r are queued (the communicator path hooks its all-reduce there).
 template <typename F>
-int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int sample, int apply_p, F after_round) {
+int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int apply_p, F after_round) {
     const int64_t R = (int64_t)bounds.size() - 1;
     // staging rows: two per event of the largest round, addressed with 31-bit byte offsets
     int64_t widest = 0;
@@ -263,7 +258,7 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
     int rc;
     if (!ne.empty()) {      // prologue: negatives + touch counts of the first round
         const int64_t r0 = ne[0];
-        if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], 1, sample, apply_p))) return rc;
+        if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], 1, apply_p))) return rc;
     }
     size_t pos = 0;
     for (int64_t r = 0; r < R; ++r) {
@@ -271,7 +266,7 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
             const int64_t e0 = bounds[(size_t)r], e1 = bounds[(size_t)r + 1];
             int64_t n0 = 0, n1 = 0;
             if (pos + 1 < ne.size()) { n0 = bounds[(size_t)ne[pos + 1]]; n1 = bounds[(size_t)ne[pos + 1] + 1]; }
-            if ((rc = launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), sample, apply_p))) return rc;
+            if ((rc = launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), apply_p))) return rc;
             ++pos;
         }
         if ((rc = after_round(r))) return rc;
@@ -511,7 +506,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
     if ((rc = zero_scalars(c))) return rc;
     std::vector<int64_t> bounds(round_ptr, round_ptr + n_rounds + 1);
-    if ((rc = run_rounds(c, a, bounds, 0, 1, [](int64_t) { return YUE_OK; }))) return rc;
+    if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) return rc;
     HIPCHK(hipGetLastError());
     return read_scalars(c, nll_out, nullptr, nullptr);
 }
@@ -555,15 +550,13 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     int rc = zero_scalars(c);
     if (rc) return rc;
     const int64_t E = c->E;
-    // negatives of the whole epoch in one pass (same counter-based draws as the per-round fused sampler,
-    // which shares the chip with the update waves of the previous round and costs more there)
-    const int fused_sampler = c->opt_epoch_sampler == 1;
-    if (!fused_sampler && E > 0) hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, a, E);
+    // negatives of the whole epoch in one pass
+    if (E > 0) hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, a, E);
     std::vector<int64_t> bounds;
     if (!c->comm) {
         for (int64_t e0 = 0; e0 < E; e0 += round_events) bounds.push_back(e0);
         bounds.push_back(E);
-        if ((rc = run_rounds(c, a, bounds, fused_sampler, 1, [](int64_t) { return YUE_OK; }))) return rc;
+        if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) return rc;
     } else {
         // Same user blocks on every rank: the block width comes from the job-wide event count.
         double etot = (double)E;
@@ -591,7 +584,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
                                c->P.p, c->dP.p, first, count);
             return YUE_OK;
         };
-        if ((rc = run_rounds(c, a, bounds, fused_sampler, 0, after))) return rc;
+        if ((rc = run_rounds(c, a, bounds, 0, after))) return rc;
         // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
         HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
@@ -649,7 +642,6 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
-    if (key == "epoch_sampler") { c->opt_epoch_sampler = value != 0; return YUE_OK; }
 #ifdef YUE_STAMPS
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
 #endif
@@ -667,9 +659,9 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
 // (100 MHz) of every update wave of the launch chosen with yue_set_option("debug_stamp_launch", i).
 int yue_debug_get_stamps(yue_ctx *c, unsigned long long *out, int64_t max_waves, int64_t *n_waves) {
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int64_t w = std::min(max_waves, c->stamp_waves + c->stamp_prep);
+    const int64_t w = std::min(max_waves, c->stamp_waves);
     if (w > 0) HIPCHK(hipMemcpy(out, c->stamps.p, (size_t)w * 64, hipMemcpyDeviceToHost));
-    *n_waves = c->stamp_waves;          // the rows after these are the prep blocks' (start, .., end)
+    *n_waves = w;
     return YUE_OK;
 }
 #endif

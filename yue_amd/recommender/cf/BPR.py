@@ -12,7 +12,7 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
   bpr.hip=-mode epoch -round auto -seed 1
                                         throughput mode: counter-based sampler on the device,
                                         S-round semantics; -round N fixes the round size
-                                        (auto = the device's default, 43,008 events on MI355X at k=128).
+                                        (auto = the device's default, 49,152 events on MI355X at k=128).
   -gpu N                                HIP device ordinal.
   -topn true                            evalRanking returns a real top-N (descending, ties: lower item id)
                                         instead of the reference's order-dependent overwrite-scan.
