@@ -78,9 +78,10 @@ int yue_bpr_rounds(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32
 
 /*
  * One epoch over the uploaded events; negatives from the device's counter-based sampler.
- * Rounds are round_events consecutive events; 0 = the device's default, yue_default_round_events (on a
- * communicator: user-aligned blocks of about
- * that many events, identical user ranges on every rank, user-factor gradients all-reduced).
+ * Rounds are blocks of whole users holding about round_events events (0 = the device's default,
+ * yue_default_round_events): users per block = floor(round_events / (events per user) + 1/2) from the
+ * job-wide event count, the same blocks on every rank of a communicator, where the blocks' user-factor
+ * differences are all-reduced.  (yue_amd/dist.py: epoch_round_ptr restates the rule.)
  * Outputs: nll (sum of -log s over this rank's triplets), sums of squares of P and of this
  * rank's Q after the epoch (for BPR.py:59).  Any output pointer may be NULL.
  */

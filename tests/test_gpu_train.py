@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from yue_amd import synth
+from yue_amd.dist import epoch_round_ptr
 from util import gz, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -150,7 +151,7 @@ def test_fused_epoch_matches_oracle(dev, orc, m, n, d, k, W):
     seed = 987654321
     Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
-    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     for epoch in range(2):
         # integer work: the device sampler's negatives are bit-exact with the oracle's
         j_gpu = dev.sample_negatives(seed, epoch)
@@ -179,7 +180,7 @@ def test_round_kernel_under_heavy_contention_and_many_wave_passes(orc, tpw):
     dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
     Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
-    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     for epoch in range(2):
         j = orc.sample_counter(5, epoch, ev_u, n, data['indptr'], data['indices'])
         nll, _, _ = dev.bpr_epoch(5, epoch, W, 0.01, 0.01, 0.01)
@@ -198,7 +199,7 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=21)
     Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
-    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     j = orc.sample_counter(9, 0, ev_u, n, data['indptr'], data['indices'])
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
     for tpw, stage in [(0, 1), (0, 0), (4, 1), (2, 0)]:
@@ -232,7 +233,7 @@ def test_default_round_size_is_one_resident_wave_set(orc):
     assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(out[1][0]) and rel_err(out[0][1], out[1][1]) < TOL and rel_err(out[0][2], out[1][2]) < TOL
     E = len(ev_u)
     j = orc.sample_counter(3, 0, ev_u, n, data['indptr'], data['indices'])
-    rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     Po, Qo = P0.copy(), Q0.copy()
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
     assert rel_err(out[0][1], Po) < TOL and rel_err(out[0][2], Qo) < TOL and abs(out[0][0] - nll_o) <= 1e-9 * abs(nll_o)
@@ -256,7 +257,7 @@ def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):
     assert set(j_orc[:39].tolist()) <= {39, -1}
     nll, _, _ = dev.bpr_epoch(77, 0, 16, 0.02, 0.01, 0.01)
     Po, Qo = P0.copy(), Q0.copy()
-    rp = np.array([0, 16, 32, 41], np.int64)
+    rp = np.array(epoch_round_ptr(ev_ptr, 16), np.int64)
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j_orc, rp, 0.02, 0.01, 0.01)
     P, Q = dev.get_factors()
     assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
@@ -283,7 +284,7 @@ def test_user_factors_beyond_two_gib(orc):
         nll, sp, _ = dev.bpr_epoch(6, 0, W, 0.02, 0.01, 0.01)
         P, Q = dev.get_factors()
         Po, Qo = P0.copy(), Q0.copy()
-        rp = np.unique(np.concatenate([np.arange(0, E, W), [E]])).astype(np.int64)
+        rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
         nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o)
         assert rel_err(P[-1000:], Po[-1000:]) < TOL and not np.array_equal(P[-1000:], P0[-1000:])
@@ -357,7 +358,7 @@ def test_degenerate_shapes(orc, m, n, k):
     nll, sp, sq = dev.bpr_epoch(9, 0, 3, 0.05, 0.01, 0.02)
     Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
-    rp = np.unique(np.concatenate([np.arange(0, E, 3), [E]])).astype(np.int64)
+    rp = np.array(epoch_round_ptr(ev_ptr, 3), np.int64)
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.05, 0.01, 0.02)
     P, Q = dev.get_factors()
     assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)

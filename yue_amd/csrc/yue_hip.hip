@@ -105,7 +105,7 @@ struct yue_ctx {
     // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
-    hipStream_t comm_stream = nullptr;   // all-reduce + user-row apply run here, beside the next rounds
+    hipStream_t comm_stream = nullptr;   // (all-reduce +) user-row apply of yue_bpr_epoch run here, beside the next rounds
     hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
 };
 
@@ -328,6 +328,9 @@ int yue_ctx_create(int device, yue_ctx **out) {
     yue_ctx *c = new yue_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     HIPCHK(c->scal.resize(yue::kNllSlots + 8));
     *out = c;
     return YUE_OK;
@@ -552,43 +555,40 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     const int64_t E = c->E;
     // negatives of the whole epoch in one pass
     if (E > 0) hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, a, E);
+    // Rounds are blocks of whole users of about round_events events: a user never straddles rounds, so a
+    // block's user-row differences are only needed again in the next epoch -- they stay in dP, a group of
+    // blocks is summed over the ranks (on a communicator) and applied by k_apply_range on the second stream
+    // while the compute stream goes on with the next group's rounds (other users' rows of P and dP only;
+    // item rows are rank-local).  The block width comes from job-wide counts: the same blocks on every rank.
     std::vector<int64_t> bounds;
-    if (!c->comm) {
-        for (int64_t e0 = 0; e0 < E; e0 += round_events) bounds.push_back(e0);
-        bounds.push_back(E);
-        if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) return rc;
-    } else {
-        // Same user blocks on every rank: the block width comes from the job-wide event count.
-        double etot = (double)E;
+    double etot = (double)E;
+    if (c->comm) {
         if ((rc = yue_allreduce_f64(c, &etot, 1))) return rc;
         if ((rc = zero_scalars(c))) return rc;            // the all-reduce used the scalar scratch
-        const double per_user = etot / (double)c->nranks / (double)c->m;
-        const int64_t ub = std::max<int64_t>(1, (int64_t)std::llround((double)round_events / std::max(per_user, 1e-9)));
-        // all-reduce granularity: at least ~8 MB of user-factor differences per collective
-        const int64_t group = std::max<int64_t>(1, (8ll << 20) / std::max<int64_t>(1, ub * c->k * 4));
-        std::vector<int64_t> ublock;
-        for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
-        ublock.push_back(c->m); bounds.push_back(E);
-        const int64_t R = (int64_t)ublock.size() - 1;
-        auto after = [&](int64_t r) -> int {
-            if ((r + 1) % group != 0 && r + 1 != R) return YUE_OK;
-            const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
-            const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
-            // The collective and the apply of this group's user rows run on the communication stream
-            // while the compute stream goes on with the next group's rounds: those touch other users'
-            // rows of P and dP only (a user never straddles groups), and item rows are rank-local.
-            HIPCHK(hipEventRecord(c->ev_rounds, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0));
-            NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream));
-            hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->comm_stream,
-                               c->P.p, c->dP.p, first, count);
-            return YUE_OK;
-        };
-        if ((rc = run_rounds(c, a, bounds, 0, after))) return rc;
-        // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
-        HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     }
+    const double per_user = etot / (double)c->nranks / (double)c->m;
+    const int64_t ub = std::max<int64_t>(1, (int64_t)std::floor((double)round_events / std::max(per_user, 1e-9) + 0.5));
+    // apply / all-reduce granularity: at least ~8 MB of user-factor differences per group
+    const int64_t group = std::max<int64_t>(1, (8ll << 20) / std::max<int64_t>(1, ub * c->k * 4));
+    std::vector<int64_t> ublock;
+    for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
+    ublock.push_back(c->m); bounds.push_back(E);
+    const int64_t R = (int64_t)ublock.size() - 1;
+    auto after = [&](int64_t r) -> int {
+        if ((r + 1) % group != 0 && r + 1 != R) return YUE_OK;
+        const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
+        const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
+        HIPCHK(hipEventRecord(c->ev_rounds, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0));
+        if (c->comm) NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream));
+        hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->comm_stream,
+                           c->P.p, c->dP.p, first, count);
+        return YUE_OK;
+    };
+    if ((rc = run_rounds(c, a, bounds, 0, after))) return rc;
+    // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
+    HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
     return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
@@ -879,9 +879,6 @@ int yue_comm_init(yue_ctx *c, const void *id128, int rank, int nranks) {
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
-    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     c->rank = rank; c->nranks = nranks;
     return YUE_OK;
 }

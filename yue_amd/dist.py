@@ -5,6 +5,7 @@ ships the RCCL unique id, synchronises and reduces scalars between the ranks; it
 torch.distributed with the gloo backend (CPU), which the launcher
 (`python -m torch.distributed.run`) has already configured through RANK / WORLD_SIZE / MASTER_*.
 """
+import math
 import os
 
 
@@ -62,7 +63,16 @@ def user_block_width(round_events, events_total, m, world):
     """Users per round on a communicator: the same number on every rank, derived from job-wide
     counts only (mirror of the rule in csrc/yue_hip.hip: yue_bpr_epoch)."""
     per_user = float(events_total) / world / m
-    return max(1, int(round(round_events / max(per_user, 1e-9))))
+    return max(1, int(math.floor(round_events / max(per_user, 1e-9) + 0.5)))
+
+
+def epoch_round_ptr(ev_ptr, round_events, events_total=None, world=1):
+    """Round boundaries (event offsets) of yue_bpr_epoch for this rank's events: blocks of whole users,
+    user_block_width users each (the last block takes the rest)."""
+    m = len(ev_ptr) - 1
+    total = int(ev_ptr[-1]) if events_total is None else events_total
+    ub = user_block_width(round_events, total, m, world)
+    return [int(ev_ptr[u]) for u in range(0, m, ub)] + [int(ev_ptr[-1])]
 
 
 def attach_device(dev, cp):
