@@ -556,10 +556,11 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     // negatives of the whole epoch in one pass
     if (E > 0) hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, a, E);
     // Rounds are blocks of whole users of about round_events events: a user never straddles rounds, so a
-    // block's user-row differences are only needed again in the next epoch -- they stay in dP, a group of
-    // blocks is summed over the ranks (on a communicator) and applied by k_apply_range on the second stream
-    // while the compute stream goes on with the next group's rounds (other users' rows of P and dP only;
-    // item rows are rank-local).  The block width comes from job-wide counts: the same blocks on every rank.
+    // block's user-row differences are only needed again in the next epoch -- they stay in dP and a group of
+    // blocks is applied by k_apply_range.  On a communicator the group is first summed over the ranks, and
+    // both run on the second stream while the compute stream goes on with the next group's rounds (other
+    // users' rows of P and dP only; item rows are rank-local).  The block width comes from job-wide counts:
+    // the same blocks on every rank.
     std::vector<int64_t> bounds;
     double etot = (double)E;
     if (c->comm) {
@@ -578,11 +579,18 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         if ((r + 1) % group != 0 && r + 1 != R) return YUE_OK;
         const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
         const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
+        const dim3 grid((unsigned)std::min<int64_t>(4096, (count + 255) / 256));
+        if (!c->comm) {
+            // one GPU: nothing to wait for -- apply between two rounds on the compute stream (a few microseconds per
+            // group; on a second stream its workgroups would take residency slots from the round kernel, which
+            // fills the chip exactly, and push single launches into a second wave generation)
+            hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->stream, c->P.p, c->dP.p, first, count);
+            return YUE_OK;
+        }
         HIPCHK(hipEventRecord(c->ev_rounds, c->stream));
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0));
-        if (c->comm) NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream));
-        hipLaunchKernelGGL(yue::k_apply_range, dim3((unsigned)std::min<int64_t>(4096, (count + 255) / 256)), dim3(256), 0, c->comm_stream,
-                           c->P.p, c->dP.p, first, count);
+        NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream));
+        hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->comm_stream, c->P.p, c->dP.p, first, count);
         return YUE_OK;
     };
     if ((rc = run_rounds(c, a, bounds, 0, after))) return rc;
