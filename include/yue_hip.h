@@ -124,7 +124,7 @@ int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t
 
 /* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
- *   "round_tpw" events per wave in the training round kernel: 0 = default, 2, 4, 8
+ *   "round_tpw" events per wave in the training round kernel: 0 = default (16 for k <= 64, 8 for k <= 128, else 4), 2, 4, 8, 16 (k <= 64 only)
  *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in
  *               staging rows (write-through stores, summed in event order by the last toucher);
  *               0: every contended row goes through float atomics

@@ -165,7 +165,7 @@ def test_fused_epoch_matches_oracle(dev, orc, m, n, d, k, W):
         assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
 
 
-@pytest.mark.parametrize('tpw', [2, 4, 8])
+@pytest.mark.parametrize('tpw', [2, 4, 8, 16])
 def test_round_kernel_under_heavy_contention_and_many_wave_passes(orc, tpw):
     # few items, big rounds: every item row is contended (about 40 touches per row and round, hot rows
     # several hundred), and the grid has more waves than the chip holds at once (late waves must still
