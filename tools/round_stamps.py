@@ -44,9 +44,7 @@ buf = np.zeros((cap, 8), np.uint64)
 nw = C.c_int64()
 lib.yue_debug_get_stamps(dev._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(cap), C.byref(nw))
 st = buf[:nw.value].astype(np.float64) * 0.01               # 100 MHz -> microseconds
-prep = buf[nw.value:].astype(np.float64) * 0.01
-prep = prep[prep[:, 0] > 0]
-t0 = min(st[:, 0].min(), prep[:, 0].min()) if len(prep) else st[:, 0].min()
+t0 = st[:, 0].min()
 names = ['header (scalar loads)', 'row gathers', 'dots + sigmoids', 'issue of stores / atomics', 'drain own stores',
          'count decrements', 'last-toucher rewrites']
 print('waves %d   launch span (first start .. last end) %.1f us' % (nw.value, st[:, 7].max() - t0))
@@ -59,10 +57,6 @@ life = st[:, 7] - st[:, 0]
 print('%-28s mean %6.2f  p50 %6.2f  p99 %6.2f us' % ('wave lifetime', life.mean(), np.percentile(life, 50), np.percentile(life, 99)))
 for q in range(8):
     print('phase boundary %d reached: first %.1f  mean %.1f  last %.1f us' % (q, st[:, q].min() - t0, st[:, q].mean() - t0, st[:, q].max() - t0))
-if len(prep):
-    print('prep blocks %d: start first %.1f last %.1f, end mean %.1f last %.1f us; duration mean %.2f p99 %.2f' % (
-        len(prep), prep[:, 0].min() - t0, prep[:, 0].max() - t0, prep[:, 7].mean() - t0, prep[:, 7].max() - t0,
-        (prep[:, 7] - prep[:, 0]).mean(), np.percentile(prep[:, 7] - prep[:, 0], 99)))
 blk = np.arange(nw.value) // 4
 print('mean wave lifetime by (block % 8), i.e. by XCD:', ' '.join('%.1f' % life[(blk % 8) == x].mean() for x in range(8)))
 print('mean wave end by grid decile:', ' '.join('%.1f' % (st[c:c + nw.value // 10, 7].mean() - t0) for c in range(0, nw.value - nw.value // 10 + 1, nw.value // 10)))

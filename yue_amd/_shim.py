@@ -165,7 +165,7 @@ class Device(object):
         return out.value
 
     def bpr_epoch(self, seed, epoch, round_events, lr, regU, regI):
-        """Returns (nll, sumsqP, sumsqQ) after one fused-sampler epoch."""
+        """Returns (nll, sumsqP, sumsqQ) after one epoch (device sampler + S-rounds; round_events 0 = the device default)."""
         nll, sp, sq = C.c_double(), C.c_double(), C.c_double()
         self._chk(self._lib.yue_bpr_epoch(self._ctx, C.c_uint64(seed), C.c_uint32(epoch), C.c_int64(round_events), C.c_double(lr), C.c_double(regU),
                                           C.c_double(regI), C.byref(nll), C.byref(sp), C.byref(sq)))

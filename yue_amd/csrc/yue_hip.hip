@@ -1,6 +1,6 @@
 // libyue_hip.so -- C ABI (include/yue_hip.h) over the gfx950 kernels.
 // Host side: device buffers behind an opaque context, dependency levelling for exact replay,
-// round scheduling for the fused epoch, RCCL all-reduce of user-factor differences.
+// round scheduling of an epoch, RCCL all-reduce of user-factor differences.
 #include "../../include/yue_hip.h"
 
 #include <hip/hip_runtime.h>
