@@ -1,0 +1,127 @@
+"""GPU parity at BASELINE.json's full sizes, through the C ABI.
+
+  * config 3 (1M users x 200K items, k=128, 50M triplets, the device's default round size): one full
+    epoch against the oracle's restatement of the same rounds (oracle/bpr_oracle.c: orc_bpr_rounds) --
+    the bench workload itself, at the real Zipf contention and the default W;
+  * one GPU's share of config 4 (10M users -> 5.1 GB of replicated user factors, a 125K-item shard,
+    60M events) through the communicator code path (1-rank RCCL communicator: all-reduce + range apply
+    on the second stream) against the same oracle (world = 1: the sharded spec IS the S-round oracle
+    with rounds cut at user blocks, tests/test_dist_cpu.py::test_one_rank_spec_equals_plain_rounds);
+  * config 2 (100K x 50K, k=64): how far one S-round epoch (the throughput semantics) lands from the
+    reference's strictly sequential loop (recommender/cf/BPR.py:40-62, orc_bpr_sequential) on the same
+    negatives -- the semantic deviation, with a stated bound.
+
+Tolerances: factor matrices within 1e-5 rel fp32 (BASELINE.json north_star; rel = max|a-b| / max|b|), the
+element-wise figure is printed and bounded beside it; loss to 1e-9; the sampler's integers bit-exact.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from yue_amd import synth
+from yue_amd.dist import epoch_round_ptr
+from util import rel_err, rel_err_elem
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+LR, REG_U, REG_I = 0.02, 0.01, 0.01          # bench.py's hyper-parameters (BPR.conf)
+
+
+def _fresh_device():
+    from yue_amd._shim import Device
+    return Device(0, raise_errors=True)
+
+
+def _epoch_vs_oracle(orc, dev, data, P0, Q0, seed, W, tag):
+    m, n = P0.shape[0], Q0.shape[0]
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    t0 = time.time()
+    j_gpu = dev.sample_negatives(seed, 0)
+    j_orc = orc.sample_counter(seed, 0, ev_u, n, data['indptr'], data['indices'])
+    assert np.array_equal(j_gpu, j_orc)                      # integer work: bit-exact
+    nll, sp, sq = dev.bpr_epoch(seed, 0, W, LR, REG_U, REG_I)
+    P, Q = dev.get_factors()
+    if W == 0:
+        W = dev.default_round_events()
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
+    Po, Qo = P0, Q0                                           # the oracle works in place on the initial arrays
+    nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j_orc, rp, LR, REG_U, REG_I)
+    eP, eQ = rel_err(P, Po), rel_err(Q, Qo)
+    xP, xQ = rel_err_elem(P, Po), rel_err_elem(Q, Qo)
+    print('%s: W=%d rounds=%d  rel_err P %.2e Q %.2e  element-wise (|b|>1e-3) P %.2e Q %.2e  nll %.6f vs %.6f  bit-equal Q %.3f  (%.0f s)'
+          % (tag, W, len(rp) - 1, eP, eQ, xP, xQ, nll, nll_o, float(np.mean(Q == Qo)), time.time() - t0))
+    assert eP < TOL and eQ < TOL
+    assert xP < 1e-3 and xQ < 1e-3                            # element-wise, elements above 1e-3 (1 % of the value range)
+    assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
+
+
+def test_config3_full_epoch_matches_oracle(orc):
+    # BASELINE config 3 = the bench workload: same generator seeds as bench.py, default round size
+    m, n, d, k = 1000000, 200000, 50, 128
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    dev = _fresh_device()
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'C3')
+    finally:
+        dev.close()
+
+
+def test_config4_shard_through_the_communicator_path(orc):
+    # one rank's share of BASELINE config 4 on a 1-rank communicator: user blocks, in-place RCCL all-reduce of the
+    # blocks' user-factor differences, k_apply_range on the second stream, P / dP beyond 2 GiB
+    from yue_amd._shim import comm_unique_id
+    m, n, d, k = 10000000, 125000, 6, 128
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    rng = np.random.default_rng(20260002)
+    P0 = rng.random((m, k), dtype=np.float32) / 10
+    Q0 = rng.random((n, k), dtype=np.float32) / 10
+    dev = _fresh_device()
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        dev.comm_init(comm_unique_id(), 0, 1)
+        _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'C4 shard (communicator path)')
+    finally:
+        dev.close()
+
+
+def test_config2_round_semantics_vs_the_sequential_loop(orc):
+    # How far does ONE epoch of the throughput semantics (S-round, default W) land from the reference's strictly
+    # sequential loop on identical negatives?  Both start from the same factors; the distance is compared with
+    # the distance the epoch itself travels.
+    m, n, d, k = 100000, 50000, 50, 64
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    E = len(ev_u)
+    dev = _fresh_device()
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        W = dev.default_round_events()
+        j = dev.sample_negatives(20260003, 0)
+        nll_r, _, _ = dev.bpr_epoch(20260003, 0, W, LR, REG_U, REG_I)
+        Pr, Qr = dev.get_factors()
+    finally:
+        dev.close()
+    Ps, Qs = P0.copy(), Q0.copy()
+    nll_s = orc.bpr_sequential(Ps, Qs, ev_u, data['ev_i'], j, LR, REG_U, REG_I)
+
+    def rms(a):
+        return float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+    moved_P, moved_Q = rms(Ps - P0), rms(Qs - Q0)
+    dist_P, dist_Q = rms(Pr - Ps), rms(Qr - Qs)
+    dloss = abs(nll_r - nll_s) / nll_s
+    print('C2, one epoch, W=%d: nll/triplet sequential %.6f  S-round %.6f  (rel diff %.2e);  RMS distance S-round vs sequential '
+          'P %.3e Q %.3e  against RMS movement of the epoch P %.3e Q %.3e  (ratio P %.3f Q %.3f);  norm-wise rel P %.2e Q %.2e'
+          % (W, nll_s / E, nll_r / E, dloss, dist_P, dist_Q, moved_P, moved_Q, dist_P / moved_P, dist_Q / moved_Q,
+             rel_err(Pr, Ps), rel_err(Qr, Qs)))
+    # stated bounds: the epoch's loss within 1 %, and the two end points much closer to each other than either is to the start
+    assert dloss < 1e-2
+    assert dist_P < 0.25 * moved_P and dist_Q < 0.25 * moved_Q

@@ -53,3 +53,15 @@ def mask_rows(indptr, indices, users):
 def rel_err(a, b):
     """max |a-b| / max |b| -- the '1e-5 rel fp32' yardstick of BASELINE.json."""
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / np.abs(b).max())
+
+
+def rel_err_elem(a, b, floor=1e-3):
+    """Element-wise companion of rel_err: max |a-b| / |b| over the elements with |b| > floor
+    (factors live in [0, 0.1): the floor keeps the near-zero elements, whose relative error is
+    unbounded by construction, out of the quotient)."""
+    a = a.astype(np.float64).ravel()
+    b = b.astype(np.float64).ravel()
+    big = np.abs(b) > floor
+    if not big.any():
+        return 0.0
+    return float((np.abs(a[big] - b[big]) / np.abs(b[big])).max())
