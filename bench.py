@@ -24,7 +24,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from yue_amd import synth            # noqa: E402
+from yue_amd import _shim          # noqa: E402
 from yue_amd._shim import Device   # noqa: E402
+if os.environ.get('YUE_LIB'):         # tuning experiments: another build of the library
+    _shim.LIB_PATH = os.environ['YUE_LIB']
 from yue_amd.dist import ControlPlane, attach_device   # noqa: E402
 
 WORKLOADS = {
