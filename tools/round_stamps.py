@@ -24,7 +24,6 @@ ap.add_argument('--round', type=int, default=32768)
 ap.add_argument('--stage', type=int, default=1)
 ap.add_argument('--tpw', type=int, default=0)
 ap.add_argument('--launch', type=int, default=700)
-ap.add_argument('--kernel', type=int, default=3, help='3: no retire protocol (default), 2: pipelined, 1: one batch per wave')
 args = ap.parse_args()
 
 _shim.LIB_PATH = os.path.join(ROOT, 'yue_amd', 'csrc', 'libyue_hip_stamps.so')
@@ -33,7 +32,6 @@ data = synth.make_arrays(args.users, args.items, args.d)
 P, Q = synth.init_factors(args.users, args.items, args.k)
 dev.set_factors(P, Q)
 dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
-dev.set_option('round_kernel', args.kernel)
 dev.set_option('round_stage', args.stage)
 if args.tpw:
     dev.set_option('round_tpw', args.tpw)
@@ -49,18 +47,12 @@ st = buf[:nw.value].astype(np.float64) * 0.01               # 100 MHz -> microse
 t0 = st[:, 0].min()
 names = ['header (scalar loads)', 'row gathers', 'dots + sigmoids', 'issue of stores / atomics', 'drain own stores',
          'count decrements', 'last-toucher rewrites']
-if args.kernel == 3:
-    names = ['header (scalar loads)', 'row gathers (+ counts, slot tables)', 'hot pending + tickets issued + dots + sigmoids', 'issue of stores / tagged rows / atomics',
-             'last-toucher rewrites (polls)', 'rare counter path', 'ticket returns + slot publish']
-if args.kernel == 2:
-    names = ['header + issue of group 0 gathers', 'group 0 (wait, evaluate, store; group 1 gathers issued)', 'group 1', 'remaining groups',
-             'tab reads + tickets + drain', 'count decrements', 'last-toucher rewrites']
 print('waves %d   launch span (first start .. last end) %.1f us' % (nw.value, st[:, 7].max() - t0))
 print('wave start  : mean %.1f  p50 %.1f  p99 %.1f  max %.1f us after the first' % (
     (st[:, 0] - t0).mean(), np.percentile(st[:, 0] - t0, 50), np.percentile(st[:, 0] - t0, 99), (st[:, 0] - t0).max()))
 for q, name in enumerate(names):
     dlt = st[:, q + 1] - st[:, q]
-    print('%-58s mean %6.2f  p50 %6.2f  p99 %6.2f us' % (name, dlt.mean(), np.percentile(dlt, 50), np.percentile(dlt, 99)))
+    print('%-28s mean %6.2f  p50 %6.2f  p99 %6.2f us' % (name, dlt.mean(), np.percentile(dlt, 50), np.percentile(dlt, 99)))
 life = st[:, 7] - st[:, 0]
 print('%-28s mean %6.2f  p50 %6.2f  p99 %6.2f us' % ('wave lifetime', life.mean(), np.percentile(life, 50), np.percentile(life, 99)))
 for q in range(8):

@@ -68,18 +68,6 @@ struct yue_ctx {
     // staged item rows (2 per event of the widest round) live behind the n item rows in the Q allocation,
     // so that "new row in place" and "new row to my staging row" are the same store with another offset
     bool staged = false;                         // the running call uses the staging rows
-    // round kernel without a retire protocol (k_round3): wide slot tables, tagged staging rows, hot rows
-    DevBuf<uint32_t> tabw0, tabw1;               // kTabMax words per item row, even / odd round
-    DevBuf<float> tstage;                        // 2 tagged staging rows per event of the widest round (8 bytes per element)
-    uint32_t round_tag = 0;                      // tag of the last launched round (never 0)
-    std::vector<int32_t> h_pos_count;            // host: events per positive item (hot-row selection)
-    DevBuf<uint16_t> hot_of;                     // per item: index in the hot set + 1, 0 = not hot
-    DevBuf<int32_t> hot_rows, ev_h, err_flag;    // hot set (item ids); per-event hot marks; poll give-up flag
-    DevBuf<float> hq0, hq1, hq2;                 // pending sums of the hot rows, three buffers in rotation
-    int nhot = 0;
-    int64_t hot_for_round = -1;                  // round size the hot set was chosen for
-    int hot_k = 0;
-    int opt_hot_lambda_x100 = 200;               // a row is hot when it expects at least this many touches per round (x 0.01)
 #ifdef YUE_STAMPS
     DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
     int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0;
@@ -99,9 +87,7 @@ struct yue_ctx {
     // options (yue_set_option)
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
-    int opt_round_kernel = 1;            // yue_bpr_epoch: 3 = no retire protocol (k_round3, default), 2 = pipelined (k_round2), 1 = one batch per wave (k_round)
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
-    int opt_debug_skip = 0;              // timing experiments only
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
     // kernel timing
     int timing_stride = 0;
@@ -154,18 +140,11 @@ void launch_level(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1) {
     }
 }
 
-
 int tpw_of(const yue_ctx *c) {
-    const int kr = kr_of(c->k);
-    if (c->opt_round_kernel == 2) {
-        // events per wave of the pipelined kernel (any value 1..64; whole groups are cheapest)
-        if (c->opt_round_tpw) return c->opt_round_tpw;
-        return kr == 4 ? 16 : 32;
-    }
-    if (c->opt_round_kernel == 3) return kr == 4 ? 4 : kr == 2 ? 8 : 16;
     if (c->opt_round_tpw) return c->opt_round_tpw;
     // measured: k = 128 (C3): 8 events per wave 53.9 ms/epoch, 4 -> 58.7, 16 -> 60.7; k = 64 (C2, half the row registers):
     // 16 events per wave 5.2 ms/epoch, 8 -> 5.7
+    const int kr = kr_of(c->k);
     return kr == 4 ? 4 : kr == 2 ? 8 : 16;
 }
 
@@ -176,34 +155,21 @@ int default_round_events(yue_ctx *c, int64_t *out) {
     const int tpw = tpw_of(c);
     int per_cu = 0, cus = 0;
     hipError_t e = hipSuccess;
-    if (c->opt_round_kernel == 3) {
-        switch (kr_of(c->k)) {
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round3<1, 16>, 256, 0); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round3<2, 8>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round3<4, 4>, 256, 0); break;
-        }
-    } else if (c->opt_round_kernel == 2) {
-        switch (kr_of(c->k)) {
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round2<1, 8>, 256, 0); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round2<2, 8>, 256, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round2<4, 4>, 256, 0); break;
-        }
-    } else {
-        switch (kr_of(c->k) * 16 + tpw) {
-            case 1 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 8>, 256, 0); break;
-            case 1 * 16 + 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 16>, 256, 0); break;
-            case 2 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 8>, 256, 0); break;
-            case 4 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<4, 4>, 256, 0); break;
-            case 1 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 4>, 256, 0); break;
-            case 2 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 4>, 256, 0); break;
-            case 1 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 2>, 256, 0); break;
-            case 2 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 2>, 256, 0); break;
-            default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
-        }
+    switch (kr_of(c->k) * 16 + tpw) {
+        case 1 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 8>, 256, 0); break;
+        case 1 * 16 + 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 16>, 256, 0); break;
+        case 2 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 8>, 256, 0); break;
+        case 4 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<4, 4>, 256, 0); break;
+        case 1 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 4>, 256, 0); break;
+        case 2 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 4>, 256, 0); break;
+        case 1 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 2>, 256, 0); break;
+        case 2 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 2>, 256, 0); break;
+        default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
     }
     HIPCHK(e);
-    // The round kernels use about 100 SGPRs; a CU admits at most floor(800 / (ceil(sgpr / 16) * 16 + 16)) = 6 workgroups
-    // of such a kernel whatever the occupancy query says (MI355X_MICROARCH.md, residency rule).
+    // The round kernels use all 106 SGPRs (yue_amd/csrc/resource_usage.txt); a CU admits at most
+    // floor(800 / (ceil(106 / 16) * 16 + 16)) = 6 workgroups of them whatever the occupancy query says
+    // (MI355X_MICROARCH.md, residency rule; seen on C2: the query answers 7, a round sized for 7 runs as two generations).
     per_cu = std::min(per_cu, 6);
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     const double slots = (double)per_cu * (double)cus;                    // resident workgroups of 256 threads
@@ -225,7 +191,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     uint32_t *tab[2] = {c->tab0.p, c->tab1.p};
     ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1]; ra.staged = c->staged ? 1 : 0;
     ra.apply_p = apply_p;
-    ra.debug_skip = c->opt_debug_skip;
     const int tpw = tpw_of(c);
     const int64_t waves = (std::max(e1 - e0, n1 - n0) + tpw - 1) / tpw;      // every wave: tickets of the next round + its update batch
     const int64_t blocks = (waves + 3) / 4;
@@ -254,13 +219,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 #else
     const yue::TrainArgs &a = a_in;
 #endif
-    if (c->opt_round_kernel == 2) {
-        switch (kr_of(c->k)) {
-            case 1: hipLaunchKernelGGL((yue::k_round2<1, 8>), grid, block, 0, c->stream, a, ra, tpw); break;
-            case 2: hipLaunchKernelGGL((yue::k_round2<2, 8>), grid, block, 0, c->stream, a, ra, tpw); break;
-            default: hipLaunchKernelGGL((yue::k_round2<4, 4>), grid, block, 0, c->stream, a, ra, tpw); break;
-        }
-    } else
     switch (kr_of(c->k) * 16 + tpw) {
         case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round<1, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         case 1 * 16 + 16: hipLaunchKernelGGL((yue::k_round<1, 16>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
@@ -323,144 +281,6 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
         if ((rc = after_round(r))) return rc;
     }
     return YUE_OK;
-}
-
-
-// ---- round kernel 3 (no retire protocol): hot-row set, launches -------------------------------------------------
-// Rows expected to collect at least opt_hot_lambda touches per round (positives by their share of the events,
-// negatives uniform) never go through the slot tables: their differences meet in the side buffers hq0..2.
-int prepare_hot_rows(yue_ctx *c, int64_t round_events) {
-    if (c->hot_for_round == round_events && c->hot_k == c->k) return YUE_OK;
-    const int64_t n = c->n, E = std::max<int64_t>(c->E, 1);
-    const double lam_min = 0.01 * c->opt_hot_lambda_x100, w = (double)std::min<int64_t>(round_events, E);
-    std::vector<std::pair<int32_t, int32_t>> cand;           // (-count, item)
-    for (int64_t x = 0; x < n; ++x) {
-        const double lam = (double)c->h_pos_count[(size_t)x] * w / (double)E + w / (double)n;
-        if (lam >= lam_min) cand.emplace_back(-c->h_pos_count[(size_t)x], (int32_t)x);
-    }
-    const size_t cap = 16384;
-    if (cand.size() > cap) { std::partial_sort(cand.begin(), cand.begin() + cap, cand.end()); cand.resize(cap); }
-    std::vector<uint16_t> hot_of((size_t)n, 0);
-    std::vector<int32_t> rows(std::max<size_t>(cand.size(), 1), 0);
-    std::sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) { return x.second < y.second; });
-    for (size_t h = 0; h < cand.size(); ++h) { rows[h] = cand[h].second; hot_of[(size_t)cand[h].second] = (uint16_t)(h + 1); }
-    c->nhot = (int)cand.size();
-    HIPCHK(c->hot_of.resize((size_t)n)); HIPCHK(c->hot_rows.resize(rows.size()));
-    const size_t hq = std::max<size_t>((size_t)c->nhot * c->k, 1);
-    HIPCHK(c->hq0.resize(hq)); HIPCHK(c->hq1.resize(hq)); HIPCHK(c->hq2.resize(hq));
-    HIPCHK(c->ev_h.resize((size_t)std::max<int64_t>(c->E, 1))); HIPCHK(c->err_flag.resize(1));
-    HIPCHK(hipMemcpyAsync(c->hot_of.p, hot_of.data(), (size_t)n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->hot_rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->hq0.p, 0, hq * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->hq1.p, 0, hq * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->hq2.p, 0, hq * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->err_flag.p, 0, sizeof(int32_t), c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));                 // the host vectors go out of scope
-    c->hot_for_round = round_events; c->hot_k = c->k;
-    return YUE_OK;
-}
-
-// One launch of k_round3: update [e0,e1) (hot rotation step `rot`), take the tickets of [n0,n1).
-int launch_round3(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t n0, int64_t n1, int parity, int rot) {
-    unsigned long long *cnt[2] = {c->cnt0.p, c->cnt1.p};
-    uint32_t *tab[2] = {c->tabw0.p, c->tabw1.p};
-    float *hq[3] = {c->hq0.p, c->hq1.p, c->hq2.p};
-    yue::Round3Args ra{};
-    ra.e_begin = e0; ra.e_end = e1; ra.n_begin = n0; ra.n_end = n1;
-    ra.cnt_cur = cnt[parity]; ra.cnt_next = cnt[parity ^ 1]; ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1];
-    if (e1 > e0) { if (++c->round_tag == 0u) c->round_tag = 1u; }
-    ra.tag = c->round_tag;
-    ra.ev_h = c->ev_h.p;
-    ra.hq_acc = hq[rot % 3]; ra.hq_zero = hq[(rot + 1) % 3]; ra.hq_read = hq[(rot + 2) % 3];
-    ra.nhot = c->nhot;
-    ra.err_flag = c->err_flag.p;
-    const int tpw = tpw_of(c);
-    const int64_t waves = (std::max(e1 - e0, n1 - n0) + tpw - 1) / tpw;
-    const int64_t blocks = (waves + 3) / 4;
-    if (blocks == 0) return YUE_OK;
-    ra.event_blocks = (int32_t)blocks;
-    const int64_t hot_blocks = (e1 > e0 && c->nhot > 0) ? std::min<int64_t>(64, (c->nhot + 3) / 4) : 0;
-    const bool timed = e1 > e0 && c->timing_stride > 0 && (c->launch_counter++ % c->timing_stride) == 0;
-    if (timed) {
-        if (c->ev_used == c->ev_pool.size()) {
-            hipEvent_t s, t;
-            HIPCHK(hipEventCreate(&s));
-            HIPCHK(hipEventCreate(&t));
-            c->ev_pool.emplace_back(s, t);
-            c->ev_triplets.push_back(0);
-        }
-        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].first, c->stream));
-    }
-    const dim3 grid((unsigned)(blocks + hot_blocks)), block(256);
-#ifdef YUE_STAMPS
-    yue::TrainArgs a = a_in;
-    a.stamps = nullptr;
-    if (e1 > e0 && c->update_launches++ == c->stamp_launch) {
-        HIPCHK(c->stamps.resize((size_t)waves * 8));
-        HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)waves * 64, c->stream));
-        a.stamps = c->stamps.p;
-        c->stamp_waves = (e1 - e0 + tpw - 1) / tpw;
-    }
-#else
-    const yue::TrainArgs &a = a_in;
-#endif
-    switch (kr_of(c->k)) {
-        case 1: hipLaunchKernelGGL((yue::k_round3<1, 16>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, c->ev_h.p); break;
-        case 2: hipLaunchKernelGGL((yue::k_round3<2, 8>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, c->ev_h.p); break;
-        default: hipLaunchKernelGGL((yue::k_round3<4, 4>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, c->ev_h.p); break;
-    }
-    if (timed) {
-        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
-        c->ev_triplets[c->ev_used] = e1 - e0;
-        c->ev_used++;
-    }
-    return YUE_OK;
-}
-
-// folds the hot rows' pending sums (in the buffer the last round accumulated into) into the item rows
-int fold_hot_rows(yue_ctx *c, int rot_last) {
-    if (c->nhot == 0 || rot_last < 0) return YUE_OK;
-    float *hq[3] = {c->hq0.p, c->hq1.p, c->hq2.p};
-    hipLaunchKernelGGL(yue::k_hot_fold, dim3((unsigned)std::min(256, (c->nhot + 3) / 4)), dim3(256), 0, c->stream, c->Q.p, c->hot_rows.p, c->nhot, c->k,
-                       hq[rot_last % 3], hq[(rot_last + 1) % 3], hq[(rot_last + 2) % 3]);
-    return YUE_OK;
-}
-
-// The rounds of an epoch with k_round3.  after_round(r) as in run_rounds; fold_at(r) says where a group of rounds ends.
-template <typename F, typename G>
-int run_rounds3(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, F after_round, G group_ends_at) {
-    const int64_t R = (int64_t)bounds.size() - 1;
-    int64_t widest = 0;
-    for (int64_t r = 0; r < R; ++r) widest = std::max(widest, bounds[(size_t)r + 1] - bounds[(size_t)r]);
-    HIPCHK(c->tstage.resize((size_t)std::max<int64_t>(4 * widest * c->k, 1)));
-    HIPCHK(c->tabw0.resize((size_t)c->n * yue::kTabMax)); HIPCHK(c->tabw1.resize((size_t)c->n * yue::kTabMax));
-    a.stage = c->tstage.p;
-    std::vector<int64_t> ne;
-    for (int64_t r = 0; r < R; ++r) if (bounds[(size_t)r + 1] > bounds[(size_t)r]) ne.push_back(r);
-    int rc;
-    if (!ne.empty()) {      // prologue: tickets of the first round
-        const int64_t r0 = ne[0];
-        if ((rc = launch_round3(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], 1, 0))) return rc;
-    }
-    size_t pos = 0;
-    int rot = 0, rot_last = -1;                             // rotation step of the hot buffers since the last fold
-    for (int64_t r = 0; r < R; ++r) {
-        if (pos < ne.size() && ne[pos] == r) {
-            const int64_t e0 = bounds[(size_t)r], e1 = bounds[(size_t)r + 1];
-            int64_t n0 = 0, n1 = 0;
-            if (pos + 1 < ne.size()) { n0 = bounds[(size_t)ne[pos + 1]]; n1 = bounds[(size_t)ne[pos + 1] + 1]; }
-            if ((rc = launch_round3(c, a, e0, e1, n0, n1, (int)(pos & 1), rot))) return rc;
-            rot_last = rot;
-            ++rot;
-            ++pos;
-        }
-        if (group_ends_at(r)) {
-            if ((rc = fold_hot_rows(c, rot_last))) return rc;
-            rot = 0; rot_last = -1;
-        }
-        if ((rc = after_round(r))) return rc;
-    }
-    return fold_hot_rows(c, rot_last);
 }
 
 int zero_scalars(yue_ctx *c) {
@@ -538,8 +358,6 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->tab0.release(); c->tab1.release();
-    c->tabw0.release(); c->tabw1.release(); c->tstage.release(); c->hot_of.release(); c->hot_rows.release(); c->ev_h.release();
-    c->err_flag.release(); c->hq0.release(); c->hq1.release(); c->hq2.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
@@ -618,9 +436,6 @@ int yue_set_interactions(yue_ctx *c, const int64_t *indptr, const int32_t *indic
             evu[(size_t)e] = (int32_t)u;
         }
     c->E = E; c->nnz = nnz;
-    c->h_pos_count.assign((size_t)n, 0);
-    for (int64_t e = 0; e < E; ++e) c->h_pos_count[(size_t)ev_i[e]]++;
-    c->hot_for_round = -1;
     c->h_ev_ptr.assign(ev_ptr, ev_ptr + m + 1);
     HIPCHK(c->indptr.resize(m + 1)); HIPCHK(c->indices.resize(std::max<int64_t>(nnz, 1)));
     HIPCHK(c->ev_u.resize(std::max<int64_t>(E, 1))); HIPCHK(c->ev_i.resize(std::max<int64_t>(E, 1))); HIPCHK(c->ev_j.resize(std::max<int64_t>(E, 1)));
@@ -703,13 +518,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
     if ((rc = zero_scalars(c))) return rc;
     std::vector<int64_t> bounds(round_ptr, round_ptr + n_rounds + 1);
-    {   // rounds may cut through a user: user rows are finished by the counter protocol (round kernels 1 / 2)
-        const int keep = c->opt_round_kernel;
-        if (keep == 3) c->opt_round_kernel = 1;
-        rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; });
-        c->opt_round_kernel = keep;
-        if (rc) return rc;
-    }
+    if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) return rc;
     HIPCHK(hipGetLastError());
     return read_scalars(c, nll_out, nullptr, nullptr);
 }
@@ -793,26 +602,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->comm_stream, c->P.p, c->dP.p, first, count);
         return YUE_OK;
     };
-    // the tagged staging rows of the widest round are addressed with 31-bit byte offsets
-    int64_t widest_round = 0;
-    for (size_t r = 0; r + 1 < bounds.size(); ++r) widest_round = std::max(widest_round, bounds[r + 1] - bounds[r]);
-    const bool k3 = c->opt_round_kernel == 3 && 16 * widest_round * (int64_t)c->k < (1ll << 31);
-    if (k3) {
-        if ((rc = prepare_hot_rows(c, round_events))) return rc;
-        if (E > 0) hipLaunchKernelGGL(yue::k_hot_marks, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, c->ev_i.p, c->ev_j.p, c->hot_of.p, E, c->ev_h.p);
-        auto group_end = [&](int64_t r) { return (r + 1) % group == 0 || r + 1 == R; };
-        if ((rc = run_rounds3(c, a, bounds, after, group_end))) return rc;
-        int32_t errf = 0;
-        HIPCHK(hipMemcpyAsync(&errf, c->err_flag.p, sizeof errf, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (errf) { (void)hipMemsetAsync(c->err_flag.p, 0, sizeof errf, c->stream); return fail(YUE_ERR_HIP, "yue_bpr_epoch: a last toucher gave up waiting for a staging row (workgroups were not dispatched in order?); set option round_kernel to 1"); }
-    } else {
-        const int keep = c->opt_round_kernel;
-        if (keep == 3) c->opt_round_kernel = 1;
-        rc = run_rounds(c, a, bounds, 0, after);
-        c->opt_round_kernel = keep;
-        if (rc) return rc;
-    }
+    if ((rc = run_rounds(c, a, bounds, 0, after))) return rc;
     // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
@@ -868,24 +658,11 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     const std::string key(name);
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
-    if (key == "hot_lambda_x100") { if (value < 25) return fail(YUE_ERR_ARG, "yue_set_option: hot_lambda_x100 must be at least 25"); c->opt_hot_lambda_x100 = (int)value; c->hot_for_round = -1; return YUE_OK; }
-    if (key == "debug_skip") { c->opt_debug_skip = (int)value; return YUE_OK; }
     if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
 #ifdef YUE_STAMPS
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
 #endif
-    if (key == "round_kernel") {
-        if (value < 1 || value > 3) return fail(YUE_ERR_ARG, "yue_set_option: round_kernel must be 1 (one batch per wave, counter protocol), 2 (pipelined, counter protocol) or 3 (no retire protocol)");
-        c->opt_round_kernel = (int)value;
-        c->opt_round_tpw = 0;
-        return YUE_OK;
-    }
     if (key == "round_tpw") {
-        if (c->opt_round_kernel == 2) {
-            if (value < 0 || value > 64) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw must be 0 (default) or 1..64 events per wave");
-            c->opt_round_tpw = (int)value;
-            return YUE_OK;
-        }
         if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw must be 0, 2, 4, 8 or 16");
         if (value == 8 && kr_of(c->k) == 4) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw 8 needs k <= 128");
         if (value == 16 && kr_of(c->k) != 1) return fail(YUE_ERR_ARG, "yue_set_option: round_tpw 16 needs k <= 64");
