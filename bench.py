@@ -6,11 +6,13 @@ event list (BASELINE config 3: 1M users x 200K items, 50 events/user = 50M tripl
 interactions resident in HBM before the timed region starts.  For N > 1 the driver launches one
 process per GPU (torch.distributed.run); every rank owns an item shard of the same shape (weak
 scaling), users are replicated, user-factor differences are all-reduced over RCCL inside the
-library; torch.distributed (gloo, yue_amd/dist.py) only ships the RCCL id, runs the barriers and
-takes the max-over-ranks time.
+library; yue_amd/dist.py (standard-library TCP, no torch in the ranks) only ships the RCCL id, runs the
+barriers and takes the max-over-ranks time.
 
-One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the library's stream) and
-`cpu_baseline` (oracle/ timed on one host core, N=1 only).
+One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the library's stream),
+`cpu_baseline` (oracle/ timed on one host core, N=1 only) and, at N=1, `secondary.c5`: the top-N scoring
+path (BASELINE config 5 on a 65,536-user slice of the same users, the factors the timed epochs left) with
+its own roofline (MFMA) and CPU baseline.
 """
 import argparse
 import json
@@ -98,15 +100,17 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
 
 
 def measured_traffic(workload, round_events):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if that profile
-    was taken on another workload / round size."""
-    try:
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-        if t['workload'] == workload and t['round_events'] == round_events:
-            return t['traffic_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
-        pass
+    """(HBM bytes per launch of the dominant kernel, where the number comes from) from the newest committed
+    rocprofv3 --pmc summary (profiles/r*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes);
+    None if that profile was taken on another workload / round size.  Not a live measurement of this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            t = json.load(open(path))
+            if t['workload'] == workload and t['round_events'] == round_events:
+                return t['traffic_bytes_per_launch'], 'committed profile %s (%s)' % (os.path.relpath(path, ROOT), t.get('taken', 'rocprofv3 --pmc passes'))
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
@@ -118,6 +122,56 @@ def _cpu_name():
     except OSError:
         pass
     return 'unknown cpu'
+
+
+def scoring_cpu_baseline(dev, data, users, ids, N, n, budget_s):
+    """oracle/ (restates base/IterativeRecommender.py:96-145) on one core, a bounded sample of the same users;
+    its lists must equal the GPU's."""
+    import oracle
+    orc = oracle.Oracle()
+    P, Q = dev.get_factors()
+
+    def rows_of(sel):
+        rws = [data['indices'][data['indptr'][x]:data['indptr'][x + 1]] for x in sel]
+        mp = np.zeros(len(sel) + 1, np.int64)
+        mp[1:] = np.cumsum([len(x) for x in rws])
+        return mp, np.concatenate(rws)
+    t1 = time.perf_counter()
+    orc.topn_scan(P, Q, users[:4], N, *rows_of(users[:4]))
+    per_user = (time.perf_counter() - t1) / 4
+    S = int(max(4, min(len(users), budget_s / per_user)))
+    t1 = time.perf_counter()
+    oid, _, _ = orc.topn_scan(P, Q, users[:S], N, *rows_of(users[:S]))
+    cdt = time.perf_counter() - t1
+    if not np.array_equal(oid, ids[:S]):
+        sys.exit('scoring bench: lists differ from the oracle')
+    return {'value': S / cdt, 'unit': 'users/s', 'cores': 1, 'kind': 'port',
+            'sample': 'first %d users of the same workload (all %d items each), oracle/bpr_oracle.c:orc_topn_scan, %.1f s on %s; lists equal the GPU lists'
+                      % (S, n, cdt, _cpu_name())}
+
+
+def secondary_scoring(dev, data, m, n, k, no_cpu):
+    """BASELINE config 5 on the first 65,536 users (all items, N = 20, training items masked) with the factors on the device."""
+    N, nu, steps = 20, min(m, 65536), 3
+    users = np.arange(nu, dtype=np.int32)
+    dev.topn_scan(users, N)
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(steps):
+        ids, sc = dev.topn_scan(users, N)
+        ms, events, rescored, used_bf16 = dev.scan_stats()
+        kms += ms
+    dt = time.perf_counter() - t0
+    ach = 2.0 * nu * n * k * steps / (kms * 1e-3)
+    peak = MFMA_BF16_PEAK if used_bf16 else MFMA_F32_PEAK
+    return {'metric': 'top-%d scoring users/sec (P.Q^T + overwrite-scan selection), k=%d' % (N, k), 'value': nu * steps / dt, 'unit': 'users/s',
+            'steps': steps, 'ms_per_step': 1e3 * dt / steps, 'dtype': 'bf16 pre-filter + f32 exact re-score' if used_bf16 else 'f32',
+            'config': {'workload': 'C5 slice: %d of the %d users x %d items, k=%d, N=%d, training items masked, factors as the timed epochs left them; '
+                                   'host copies of ids/scores included in value' % (nu, m, n, k, N),
+                       'state_machine_events_per_user': events / nu, 'exact_rescores_per_user': rescored / nu},
+            'roofline': {'bound': 'mfma', 'kernel': ('k_topn_scan_bf16<K16=%d>' % (k // 16)) if used_bf16 else 'k_topn_scan (f32 MFMA)', 'achieved': ach / 1e12,
+                         'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel_ms_per_scan': kms / steps, 'traffic': None},
+            'cpu_baseline': None if no_cpu else scoring_cpu_baseline(dev, data, users, ids, N, n, 4.0)}
 
 
 def bench_scoring(args, cp):
@@ -146,28 +200,7 @@ def bench_scoring(args, cp):
     dt = cp.reduce_max(time.perf_counter() - t0)
     cpu = None
     if cp.rank == 0 and cp.world == 1 and not args.no_cpu_baseline:
-        # oracle/ (restates base/IterativeRecommender.py:96-145) on one core, bounded sample of the same users
-        import oracle
-        orc = oracle.Oracle()
-        P, Q = dev.get_factors()
-
-        def rows_of(sel):
-            rws = [data['indices'][data['indptr'][x]:data['indptr'][x + 1]] for x in sel]
-            mp = np.zeros(len(sel) + 1, np.int64)
-            mp[1:] = np.cumsum([len(x) for x in rws])
-            return mp, np.concatenate(rws)
-        t1 = time.perf_counter()
-        orc.topn_scan(P, Q, users[:4], N, *rows_of(users[:4]))
-        per_user = (time.perf_counter() - t1) / 4
-        S = int(max(4, min(len(users), 12.0 / per_user)))
-        t1 = time.perf_counter()
-        oid, _, _ = orc.topn_scan(P, Q, users[:S], N, *rows_of(users[:S]))
-        cdt = time.perf_counter() - t1
-        if not np.array_equal(oid, ids[:S]):
-            sys.exit('scoring bench: lists differ from the oracle')
-        cpu = {'value': S / cdt, 'unit': 'users/s', 'cores': 1, 'kind': 'port',
-               'sample': 'first %d users of the same workload (all %d items each), oracle/bpr_oracle.c:orc_topn_scan, %.1f s on %s; lists equal the GPU lists'
-                         % (S, n, cdt, _cpu_name())}
+        cpu = scoring_cpu_baseline(dev, data, users, ids, N, n, 12.0)
     if cp.rank == 0:
         flop = 2.0 * len(users) * n * k
         ach = flop * args.steps / (kms * 1e-3)
@@ -256,6 +289,7 @@ def main():
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--round-events', type=int, default=0, help='events per S-round; 0 = the library\'s default for this device (one resident wave set)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the scoring line (secondary.c5) of the default run')
     ap.add_argument('--scan-f32', action='store_true', help='scoring workloads: force the exact f32-MFMA kernel')
     ap.add_argument('--tpw', type=int, default=0, help='tuning: events per wave in the round kernel (0 = default)')
     ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE', help='tuning: yue_set_option(NAME, VALUE), repeatable')
@@ -302,8 +336,7 @@ def main():
     for _ in range(args.warmup):
         dev.bpr_epoch(seed, epoch, args.round_events, LR, REG_U, REG_I)
         epoch += 1
-    n_rounds = (E + args.round_events - 1) // args.round_events
-    dev.set_kernel_timing(max(1, n_rounds // 128))      # ~128 bracketed launches per epoch
+    dev.set_kernel_timing(1)                            # one HIP-event bracket around each epoch's round launches
 
     def barrier():
         dev.sync()
@@ -329,6 +362,7 @@ def main():
         value = total / dt
         ab = algorithmic_bytes(k)
         achieved = ab * k_triplets / (k_ms * 1e-3) if k_ms > 0 else 0.0
+        traffic = measured_traffic(args.workload, args.round_events)
         out = {
             'metric': 'BPR triplet-updates/sec at k=%d' % k, 'value': value, 'unit': 'triplets/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -343,11 +377,16 @@ def main():
                          'algorithmic_bytes_per_triplet': ab, 'launches_timed': k_launches,
                          'avg_launch_ms': (k_ms / k_launches) if k_launches else None,
                          'triplets_per_launch': (k_triplets / k_launches) if k_launches else None,
-                         'traffic': measured_traffic(args.workload, args.round_events)},
+                         'timing': 'HIP events on the library\'s stream around all round launches of each timed epoch (launch boundaries and the %d user-row '
+                                   'apply launches per epoch included): avg_launch_ms x launches per epoch <= ms_per_step by construction; the kernel-only average '
+                                   'is in the rocprofv3 summary under profiles/' % max(1, k_launches // max(1, args.steps) // 16),
+                         'traffic': traffic[0] if traffic else None, 'traffic_source': traffic[1] if traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             j0 = dev.sample_negatives(seed, 0)
             out['cpu_baseline'] = cpu_baseline(data, P0, Q0, j0, k)
+        if world == 1 and not args.no_secondary and not args.force_comm and args.workload == 'c3':
+            out['secondary'] = {'c5': secondary_scoring(dev, data, m, n, k, args.no_cpu_baseline)}
         print(json.dumps(out))
     dev.close()
     cp.close()

@@ -89,6 +89,13 @@ int yue_bpr_epoch(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int64_t round_eve
                   double lr, double regU, double regI,
                   double *nll_out, double *sumsqP_out, double *sumsqQ_out);
 
+/* The host-side schedule of yue_bpr_epoch, as a pure function (no device, no context): users per round
+ * (user_block = floor(round_events / (events_total / nranks / m) + 1/2), at least 1), rounds per apply / all-reduce
+ * group (at least ~8 MB of user-factor differences per collective) and the number of rounds.  Every rank computes
+ * the same values from job-wide counts; tests check it against yue_amd/dist.py: epoch_block_plan. */
+int yue_epoch_plan(int64_t m, int k, int64_t round_events, double events_total, int nranks,
+                   int64_t *user_block, int64_t *blocks_per_group, int64_t *n_blocks);
+
 /* The default round size for the uploaded k on this device: the events one resident set of waves of the round
  * kernel takes (a launch is then a single wave generation); 49,152 on MI355X at k = 128.  Results depend on the
  * round size: pass an explicit value where runs must be comparable across devices. */
@@ -114,8 +121,10 @@ int yue_topn_scan(yue_ctx *ctx, const int32_t *users, int64_t nu, int N,
                   const int64_t *mask_indptr, const int32_t *mask_indices,
                   int32_t *out_ids, float *out_scores);
 
-/* Timing of the dominant training kernel with HIP events on the library's stream.
- * stride = 0 disables; otherwise every stride-th launch is bracketed. */
+/* Timing of the dominant training kernel with HIP events on the library's stream: stride = 0 disables; any other
+ * value brackets ALL round launches of each yue_bpr_epoch / yue_bpr_rounds call with one event pair (launch
+ * boundaries and the interleaved user-row apply launches included).  yue_get_kernel_timing returns the summed
+ * time, the round launches and the triplets inside the brackets since the last call. */
 int yue_set_kernel_timing(yue_ctx *ctx, int stride);
 int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_timed, int64_t *triplets_timed);
 /* Last yue_topn_scan: time of its scoring kernel (HIP events), state-machine events, exact re-scores

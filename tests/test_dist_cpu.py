@@ -1,12 +1,15 @@
-"""CPU, world_size 2 over gloo: the control plane bench.py uses (id broadcast, barrier, max) and the
-sharded S-round epoch (executable spec with oracle arithmetic): the all-reduced user factors are
-identical on both ranks and equal a single-process emulation of the two shards."""
+"""CPU, world_size 2: the control plane bench.py uses (yue_amd/dist.py: standard-library TCP star -- id broadcast,
+barrier, max) and the sharded S-round epoch (executable spec with oracle arithmetic): the all-reduced user
+factors are identical on both ranks and equal a single-process emulation of the two shards.  Plus the host-side
+schedule of yue_bpr_epoch (user blocks, all-reduce groups) at BASELINE config 4's counts for 8 ranks, taken from
+the library itself (yue_epoch_plan: pure host arithmetic, no GPU) against yue_amd/dist.py."""
 import os
 import socket
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from helpers.sharded_spec import epoch_spec, shard_problem
 
@@ -21,13 +24,28 @@ def _free_port():
     return port
 
 
-def test_two_rank_sharded_epoch_over_gloo(tmp_path, orc):
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', 'helpers', 'rank_main.py'), str(tmp_path)]
-    env = dict(os.environ, OMP_NUM_THREADS='1')
-    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    assert res.returncode == 0, res.stdout.decode()[-3000:]
+def _run_two_ranks(tmp_path, through_torchrun):
+    script = os.path.join(ROOT, 'tests', 'helpers', 'rank_main.py')
+    port = _free_port()
+    if through_torchrun:
+        # as the driver launches bench.py: the launcher's own store sits on MASTER_PORT, the ranks must not collide with it
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), script, str(tmp_path)]
+        res = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS='1'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert res.returncode == 0, res.stdout.decode()[-3000:]
+        return
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, OMP_NUM_THREADS='1', RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script, str(tmp_path)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-3000:]
+
+
+@pytest.mark.parametrize('through_torchrun', [False, True])
+def test_two_rank_sharded_epoch_over_the_tcp_control_plane(tmp_path, orc, through_torchrun):
+    _run_two_ranks(tmp_path, through_torchrun)
     r0 = np.load(tmp_path / 'rank0.npz')
     r1 = np.load(tmp_path / 'rank1.npz')
     assert np.array_equal(r0['P'], r1['P'])                     # replicated user factors stay identical
@@ -80,3 +98,32 @@ def test_one_rank_spec_equals_plain_rounds(orc):
     rp = data['ev_ptr'][np.unique(np.concatenate([np.arange(0, m, ub), [m]]))]
     nll2 = orc.bpr_rounds(P2, Q2, ev_u, data['ev_i'], j, rp, 0.05, 0.01, 0.01)
     assert np.array_equal(P, P2) and np.array_equal(Q, Q2) and abs(nll - nll2) < 1e-9 * abs(nll2)
+
+
+def test_epoch_schedule_of_the_library_for_eight_ranks_on_config4():
+    # BASELINE config 4: 10M users, 500M events over 8 item shards, k = 128; the library's host arithmetic
+    # (yue_hip.hip: yue_epoch_plan, used by yue_bpr_epoch on every rank) against the Python restatement
+    from yue_amd._shim import epoch_plan
+    from yue_amd.dist import epoch_block_plan, user_block_width
+    m, k, etot = 10000000, 128, 500e6
+    for world in (1, 2, 4, 8):
+        for W in (49152, 32768, 1000, 7):
+            ub, grp, nb = epoch_plan(m, k, W, etot, world)
+            plan = epoch_block_plan(m, k, W, etot, world)
+            assert ub == user_block_width(W, etot, m, world) == plan['user_block']
+            assert grp == plan['blocks_per_group'] and nb == plan['n_blocks']
+            groups = plan['groups']
+            assert groups[0][0] == 0 and groups[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(groups, groups[1:]))           # contiguous, no user twice
+            assert all(g[2] == (g[1] - g[0]) * k for g in groups)
+            if len(groups) > 1:
+                assert min(g[2] * 4 for g in groups[:-1]) >= (8 << 20) - ub * k * 4    # every full group carries about 8 MB or more
+    # 8 ranks, default round: 6.25 events per user and rank -> 7,864 users per round, 2 rounds per all-reduce
+    ub, grp, nb = epoch_plan(m, k, 49152, etot, 8)
+    assert (ub, grp, nb) == (7864, 2, 1272)
+    # a user is never split: block boundaries are user boundaries for any ragged event list
+    from yue_amd.dist import epoch_round_ptr
+    rs = np.random.RandomState(3)
+    ev_ptr = np.concatenate([[0], np.cumsum(rs.randint(0, 9, size=1000))])
+    rp = epoch_round_ptr(ev_ptr, 64, events_total=float(ev_ptr[-1]) * 8, world=8)
+    assert rp[0] == 0 and rp[-1] == ev_ptr[-1] and set(rp) <= set(ev_ptr.tolist())

@@ -164,6 +164,34 @@ def test_array_native_data_through_the_plugin_surface(tmp_path, capsys):
         assert a == b or abs(float(a.split(':')[1]) - float(b.split(':')[1])) < 1e-12
 
 
+def test_config2_through_the_driver_from_a_csr_file(tmp_path, capsys):
+    """BASELINE config 2 (100K users x 50K items, k=64) from a binary csr data set through the reference's own entry:
+    Config -> Yue(conf).execute() -> BPR.execute() (initModel, buildModel in epoch mode, evalRanking on ids)."""
+    from test_host_golden import _conf_text
+    from yue_amd import synth
+    from yue_amd.tool.config import Config
+    from yue_amd.yue import Yue
+    m, n, d, k = 100000, 50000, 50, 64
+    path = str(tmp_path / 'c2.npz')
+    synth.write_csr(path, m, n, d, d_test=6, seed=20260001)
+    text = _conf_text({'record': path, 'record.setup': '-format csr', 'evaluation.setup': '-target track', 'num.factors': str(k), 'num.max.iter': '3',
+                       'item.ranking': '-topN 10,20', 'output.setup': 'on -dir ' + str(tmp_path / 'results') + '/'},
+                      {'bpr.hip': '-mode epoch -round auto -seed 4 -gpu 0'})
+    conf_file = tmp_path / 'c2.conf'
+    conf_file.write_text(text)
+    np.random.seed(5)
+    Yue(Config(str(conf_file))).execute()
+    out = capsys.readouterr().out
+    assert 'BPR [1] iteration 3' in out and 'Top 20' in out
+    losses = [float(ln.split('loss = ')[1].split(',')[0]) for ln in out.splitlines() if 'iteration' in ln]
+    assert losses[2] < losses[1] < losses[0]
+    measure = open(glob.glob(str(tmp_path / 'results' / '*measure*.txt'))[0]).read()
+    prec10 = float(measure.split('Precision:')[1].split()[0])
+    assert 0.0 < prec10 < 1.0
+    lists = open(glob.glob(str(tmp_path / 'results' / '*items*.txt'))[0]).read().splitlines()
+    assert len(lists) > 0.9 * m                                  # one line per user with held-out items
+
+
 def test_save_and_load_model_round_trip(tmp_path, capsys):
     # the reference leaves saveModel / loadModel empty (base/IterativeRecommender.py:41-45); here they
     # store P and Q (.npz) and the load branch of execute() (base/recommender.py:157-159) ranks from them

@@ -23,7 +23,7 @@ SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy',
            'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
            'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
-           'yue_default_round_events',
+           'yue_default_round_events', 'yue_epoch_plan',
            'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_scores', 'yue_fism_topn_scan']
 
 
@@ -77,6 +77,17 @@ def comm_unique_id():
     if rc != OK:
         raise YueHipError(rc, lib.yue_last_error().decode())
     return bytes(buf)
+
+
+def epoch_plan(m, k, round_events, events_total, nranks):
+    """(user_block, blocks_per_group, n_blocks) of yue_bpr_epoch's schedule -- pure host arithmetic inside the library."""
+    lib = load_library()
+    ub, grp, nb = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib.yue_epoch_plan(C.c_int64(m), C.c_int(k), C.c_int64(round_events), C.c_double(events_total), C.c_int(nranks),
+                            C.byref(ub), C.byref(grp), C.byref(nb))
+    if rc != OK:
+        raise YueHipError(rc, lib.yue_last_error().decode())
+    return ub.value, grp.value, nb.value
 
 
 class Device(object):

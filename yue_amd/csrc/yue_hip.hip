@@ -91,9 +91,8 @@ struct yue_ctx {
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
     // kernel timing
     int timing_stride = 0;
-    int64_t launch_counter = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    std::vector<int64_t> ev_triplets;
+    std::vector<int64_t> ev_triplets, ev_launches;
     size_t ev_used = 0;
     // FISM (parity path): item-history factors (f64), item factors (f32), item bias (f64)
     DevBuf<double> fP, fBi, f_coef, f_x, f_hist, f_scores, f_out_sc;
@@ -107,6 +106,7 @@ struct yue_ctx {
     int rank = 0, nranks = 1;
     hipStream_t comm_stream = nullptr;   // (all-reduce +) user-row apply of yue_bpr_epoch run here, beside the next rounds
     hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
+    hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr;      // brackets of the scoring kernel (yue_get_scan_stats)
 };
 
 namespace {
@@ -195,17 +195,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     const int64_t waves = (std::max(e1 - e0, n1 - n0) + tpw - 1) / tpw;      // every wave: tickets of the next round + its update batch
     const int64_t blocks = (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
-    const bool timed = e1 > e0 && c->timing_stride > 0 && (c->launch_counter++ % c->timing_stride) == 0;
-    if (timed) {
-        if (c->ev_used == c->ev_pool.size()) {
-            hipEvent_t s, t;
-            HIPCHK(hipEventCreate(&s));
-            HIPCHK(hipEventCreate(&t));
-            c->ev_pool.emplace_back(s, t);
-            c->ev_triplets.push_back(0);
-        }
-        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].first, c->stream));
-    }
     const dim3 grid((unsigned)blocks), block(256);
 #ifdef YUE_STAMPS
     yue::TrainArgs a = a_in;
@@ -229,11 +218,6 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
         case 1 * 16 + 2: hipLaunchKernelGGL((yue::k_round<1, 2>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         case 2 * 16 + 2: hipLaunchKernelGGL((yue::k_round<2, 2>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j); break;
         default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
-    }
-    if (timed) {
-        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
-        c->ev_triplets[c->ev_used] = e1 - e0;
-        c->ev_used++;
     }
     return YUE_OK;
 }
@@ -269,6 +253,19 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
         const int64_t r0 = ne[0];
         if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], 1, apply_p))) return rc;
     }
+    // kernel timing (yue_set_kernel_timing): one HIP-event bracket around all round launches of this call
+    const bool timed = c->timing_stride > 0 && !ne.empty();
+    if (timed) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t s, t;
+            HIPCHK(hipEventCreate(&s));
+            HIPCHK(hipEventCreate(&t));
+            c->ev_pool.emplace_back(s, t);
+            c->ev_triplets.push_back(0);
+            c->ev_launches.push_back(0);
+        }
+        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].first, c->stream));
+    }
     size_t pos = 0;
     for (int64_t r = 0; r < R; ++r) {
         if (pos < ne.size() && ne[pos] == r) {
@@ -280,7 +277,26 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
         }
         if ((rc = after_round(r))) return rc;
     }
+    if (timed) {
+        HIPCHK(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
+        c->ev_triplets[c->ev_used] = bounds.back() - bounds.front();
+        c->ev_launches[c->ev_used] = (int64_t)ne.size();
+        c->ev_used++;
+    }
     return YUE_OK;
+}
+
+// After a failed round launch the touch counters and difference buffers may hold a half-finished round: clear them,
+// so that the next call starts from a clean state instead of silently producing wrong factors.
+void reset_round_state(yue_ctx *c) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->cnt0.p) (void)hipMemsetAsync(c->cnt0.p, 0, c->cnt0.n * sizeof(unsigned long long), c->stream);
+    if (c->cnt1.p) (void)hipMemsetAsync(c->cnt1.p, 0, c->cnt1.n * sizeof(unsigned long long), c->stream);
+    if (c->cntp0.p) (void)hipMemsetAsync(c->cntp0.p, 0, c->cntp0.n * sizeof(uint32_t), c->stream);
+    if (c->cntp1.p) (void)hipMemsetAsync(c->cntp1.p, 0, c->cntp1.n * sizeof(uint32_t), c->stream);
+    if (c->dP.p) (void)hipMemsetAsync(c->dP.p, 0, c->dP.n * sizeof(float), c->stream);
+    if (c->dQ.p) (void)hipMemsetAsync(c->dQ.p, 0, c->dQ.n * sizeof(float), c->stream);
+    (void)hipStreamSynchronize(c->stream);
 }
 
 int zero_scalars(yue_ctx *c) {
@@ -336,11 +352,18 @@ int yue_ctx_create(int device, yue_ctx **out) {
     HIPCHK(hipSetDevice(device));
     yue_ctx *c = new yue_ctx();
     c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
-    HIPCHK(c->scal.resize(yue::kNllSlots + 8));
+    const auto init = [c]() -> int {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&c->ev_scan0));
+        HIPCHK(hipEventCreate(&c->ev_scan1));
+        HIPCHK(c->scal.resize(yue::kNllSlots + 8));
+        return YUE_OK;
+    };
+    const int rc = init();
+    if (rc) { const std::string msg = g_err; (void)yue_ctx_destroy(c); g_err = msg; return rc; }     // nothing of a half-built context survives
     *out = c;
     return YUE_OK;
 }
@@ -348,12 +371,14 @@ int yue_ctx_create(int device, yue_ctx **out) {
 int yue_ctx_destroy(yue_ctx *c) {
     if (!c) return YUE_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->ev_rounds) (void)hipEventDestroy(c->ev_rounds);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    if (c->ev_scan0) (void)hipEventDestroy(c->ev_scan0);
+    if (c->ev_scan1) (void)hipEventDestroy(c->ev_scan1);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
@@ -364,7 +389,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release();
     c->fP.release(); c->fBi.release(); c->f_coef.release(); c->f_x.release(); c->f_hist.release(); c->f_scores.release();
     c->f_out_sc.release(); c->fQ.release(); c->f_ptr.release(); c->f_items.release(); c->f_negs.release(); c->f_ids.release(); c->f_flags.release();
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return YUE_OK;
 }
@@ -382,7 +407,8 @@ int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64
     if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: ids must fit int32");
     if (n * (int64_t)k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: the item matrix of one GPU must stay below 2 GiB (n*k*4 < 2^31): shard the items");
     HIPCHK(hipSetDevice(c->device));
-    if (c->have_inter && (m != c->m || n != c->n)) c->have_inter = false;   // new shape: interactions must be uploaded again
+    if (c->have_inter && (m != c->m || n != c->n || k != c->k)) c->have_inter = false;   // new shape (k enters the offset bounds checked by yue_set_interactions): upload the interactions again
+    if (k != c->k) c->opt_round_tpw = 0;                   // the events-per-wave option was validated against the old k
     c->m = m; c->n = n; c->k = k;
     HIPCHK(c->P.resize(m * k)); HIPCHK(c->Q.resize(n * k));
     HIPCHK(c->dP.resize(m * k)); HIPCHK(c->dQ.resize(n * k));
@@ -518,7 +544,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
     if ((rc = zero_scalars(c))) return rc;
     std::vector<int64_t> bounds(round_ptr, round_ptr + n_rounds + 1);
-    if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) return rc;
+    if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) { reset_round_state(c); return rc; }
     HIPCHK(hipGetLastError());
     return read_scalars(c, nll_out, nullptr, nullptr);
 }
@@ -576,10 +602,8 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         if ((rc = yue_allreduce_f64(c, &etot, 1))) return rc;
         if ((rc = zero_scalars(c))) return rc;            // the all-reduce used the scalar scratch
     }
-    const double per_user = etot / (double)c->nranks / (double)c->m;
-    const int64_t ub = std::max<int64_t>(1, (int64_t)std::floor((double)round_events / std::max(per_user, 1e-9) + 0.5));
-    // apply / all-reduce granularity: at least ~8 MB of user-factor differences per group
-    const int64_t group = std::max<int64_t>(1, (8ll << 20) / std::max<int64_t>(1, ub * c->k * 4));
+    int64_t ub = 1, group = 1;
+    if ((rc = yue_epoch_plan(c->m, c->k, round_events, etot, c->nranks, &ub, &group, nullptr))) return rc;
     std::vector<int64_t> ublock;
     for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
     ublock.push_back(c->m); bounds.push_back(E);
@@ -602,13 +626,25 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->comm_stream, c->P.p, c->dP.p, first, count);
         return YUE_OK;
     };
-    if ((rc = run_rounds(c, a, bounds, 0, after))) return rc;
+    if ((rc = run_rounds(c, a, bounds, 0, after))) { reset_round_state(c); return rc; }
     // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
     return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
+}
+
+int yue_epoch_plan(int64_t m, int k, int64_t round_events, double events_total, int nranks,
+                   int64_t *user_block, int64_t *blocks_per_group, int64_t *n_blocks) {
+    if (m <= 0 || k <= 0 || round_events <= 0 || nranks < 1 || !(events_total >= 0.0)) return fail(YUE_ERR_ARG, "yue_epoch_plan: bad argument");
+    const double per_user = events_total / (double)nranks / (double)m;
+    const int64_t ub = std::max<int64_t>(1, (int64_t)std::floor((double)round_events / std::max(per_user, 1e-9) + 0.5));
+    if (user_block) *user_block = ub;
+    // apply / all-reduce granularity: at least ~8 MB of user-factor differences per group
+    if (blocks_per_group) *blocks_per_group = std::max<int64_t>(1, (8ll << 20) / std::max<int64_t>(1, ub * k * 4));
+    if (n_blocks) *n_blocks = (m + ub - 1) / ub;
+    return YUE_OK;
 }
 
 int yue_default_round_events(yue_ctx *c, int64_t *out) {
@@ -620,7 +656,6 @@ int yue_default_round_events(yue_ctx *c, int64_t *out) {
 int yue_set_kernel_timing(yue_ctx *c, int stride) {
     if (!c || stride < 0) return fail(YUE_ERR_ARG, "yue_set_kernel_timing: bad argument");
     c->timing_stride = stride;
-    c->launch_counter = 0;
     c->ev_used = 0;
     return YUE_OK;
 }
@@ -630,15 +665,16 @@ int yue_get_kernel_timing(yue_ctx *c, double *total_ms, int64_t *launches, int64
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     double tot = 0.0;
-    int64_t trip = 0;
+    int64_t trip = 0, nl = 0;
     for (size_t t = 0; t < c->ev_used; ++t) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_pool[t].first, c->ev_pool[t].second));
         tot += ms;
         trip += c->ev_triplets[t];
+        nl += c->ev_launches[t];
     }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int64_t)c->ev_used;
+    if (launches) *launches = nl;
     if (triplets) *triplets = trip;
     c->ev_used = 0;
     return YUE_OK;
@@ -734,8 +770,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(c->s_norms.resize(ntile));
     hipLaunchKernelGGL(yue::k_tile_norm_max, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
     sa.tile_norm_max = c->s_norms.p;
-    hipEvent_t t0, t1;
-    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    const hipEvent_t t0 = c->ev_scan0, t1 = c->ev_scan1;
     HIPCHK(hipEventRecord(t0, c->stream));
     int rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32);
     HIPCHK(hipEventRecord(t1, c->stream));
@@ -749,7 +784,6 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, t0, t1));
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     c->scan_ms = ms;
     c->scan_events = flags[1];
     c->scan_rescored = flags[2];

@@ -134,6 +134,45 @@ class ArrayRecord(object):
         return {'ev_ptr': self.ev_ptr, 'ev_i': self.ev_i, 'indptr': self.indptr, 'indices': self.indices}
 
 
+CSR_KEYS = ('m', 'n', 'ev_ptr', 'ev_i', 'test_indptr', 'test_indices')
+
+
+def save_csr(path, m, n, ev_ptr, ev_i, test_indptr=None, test_indices=None):
+    """Binary data set for ``record.setup=-format csr`` (an uncompressed .npz of plain integer arrays):
+    m, n, ev_ptr int64[m+1], ev_i int32[E] (training events, user-major), test_indptr int64[m+1],
+    test_indices int32 (held-out items per user, sorted unique)."""
+    if test_indptr is None:
+        test_indptr, test_indices = np.zeros(int(m) + 1, np.int64), np.zeros(0, np.int32)
+    np.savez(path, m=np.int64(m), n=np.int64(n), ev_ptr=np.ascontiguousarray(ev_ptr, np.int64), ev_i=np.ascontiguousarray(ev_i, np.int32),
+             test_indptr=np.ascontiguousarray(test_indptr, np.int64), test_indices=np.ascontiguousarray(test_indices, np.int32))
+
+
+def load_csr(path, rec_type='track'):
+    """The loader behind ``record.setup=-format csr``: the counterpart of FileIO.loadDataSet + Record's id
+    assignment (reference tool/file.py:23-52, data/record.py:138-226) for data that is already integer ids.
+    Nothing in the file is executed (allow_pickle stays off); malformed files end in the reference's
+    print-and-exit convention."""
+    try:
+        with np.load(path, allow_pickle=False) as z:
+            missing = [key for key in CSR_KEYS if key not in z.files]
+            if missing:
+                print('The csr data set %s lacks the arrays: %s' % (path, ', '.join(missing)))
+                exit(-1)
+            arrays = {key: z[key] for key in CSR_KEYS}
+    except (OSError, ValueError) as err:
+        print('Cannot read the csr data set %s: %s' % (path, err))
+        exit(-1)
+    m, n = int(arrays['m']), int(arrays['n'])
+    ev_ptr, ev_i, tp, ti = arrays['ev_ptr'], arrays['ev_i'], arrays['test_indptr'], arrays['test_indices']
+    ok = (m > 0 and n > 0 and len(ev_ptr) == m + 1 and len(tp) == m + 1 and ev_ptr[0] == 0 and tp[0] == 0
+          and ev_ptr[-1] == len(ev_i) and tp[-1] == len(ti) and (np.diff(ev_ptr) >= 0).all() and (np.diff(tp) >= 0).all()
+          and (len(ev_i) == 0 or (0 <= ev_i.min() and ev_i.max() < n)) and (len(ti) == 0 or (0 <= ti.min() and ti.max() < n)))
+    if not ok:
+        print('The csr data set %s is inconsistent (sizes, offsets or ids out of range).' % path)
+        exit(-1)
+    return ArrayRecord(m, n, ev_ptr, ev_i, tp, ti, rec_type)
+
+
 def ranking_measure_ids(test_indptr, test_indices, users, ids, top, item_count):
     """evaluation/measure.py:16-66,91-101 on integer lists: ``ids[nu, N]`` are the lists of ``users``
     (int ids).  Same definitions and output format as Measure.rankingMeasure, vectorised with NumPy

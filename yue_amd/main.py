@@ -4,7 +4,7 @@ import time
 from .tool.config import Config
 from .yue import Yue
 
-MENU = {'1': 'BPR'}
+MENU = {'1': 'BPR', '2': 'FISM'}
 
 
 def main():
@@ -12,7 +12,7 @@ def main():
     print('   Yue: Library for Music Recommendation (MI355X BPR path).   ')
     print('=' * 80)
     print('CF-based Recommenders:')
-    print('1. BPR')
+    print('1. BPR   2. FISM')
     print('=' * 80)
     order = input('Please enter the num of the algorithm to run it:')
     start = time.time()

@@ -114,3 +114,13 @@ def make_test_arrays(m, n, d, d_test, indptr, indices, seed=20260001, user_chunk
     tp = np.zeros(m + 1, dtype=np.int64)
     np.cumsum(counts, out=tp[1:])
     return tp, np.concatenate(rows).astype(np.int32)
+
+
+def write_csr(path, m, n, d, d_test=6, seed=20260001):
+    """The synthetic problem as a binary csr data set (``record.setup=-format csr``): d training events and up to
+    d_test held-out items per user."""
+    from .data.arrays import save_csr
+    data = make_arrays(m, n, d, seed=seed)
+    tp, ti = make_test_arrays(m, n, d, d_test, data['indptr'], data['indices'], seed=seed)
+    save_csr(path, m, n, data['ev_ptr'], data['ev_i'], tp, ti)
+    return data, tp, ti

@@ -2,7 +2,11 @@
 
 Differences from the reference, all outside the numeric path: the class is imported with
 importlib instead of exec/eval, `mkl` is not needed, and only recommenders that exist in
-yue_amd.recommender are importable (BPR in this build).
+yue_amd.recommender are importable (BPR and FISM in this build).
+
+One addition: ``record.setup=-format csr`` makes ``record`` a binary integer data set
+(yue_amd/data/arrays.py: save_csr / load_csr) that carries its own held-out items; it goes to the
+recommender as an ArrayRecord, whatever ``evaluation.setup`` says about splitting (only ``-cv`` is refused).
 """
 import importlib
 from multiprocessing import Manager, Process
@@ -47,16 +51,25 @@ class Yue(object):
         self.measure = []
         self.config = config
         setup = LineConfig(config['record.setup'])
+        if not self.config.contains('evaluation.setup'):
+            print('Evaluation is not well configured!')
+            exit(-1)
+        self.evaluation = LineConfig(config['evaluation.setup'])
+        if setup.contains('-format') and setup['-format'] == 'csr':
+            if self.evaluation.contains('-cv'):
+                print('-cv needs the text log: a csr data set carries its own held-out items.')
+                exit(-1)
+            from .data.arrays import load_csr
+            target = self.evaluation['-target'] if self.evaluation.contains('-target') else 'track'
+            self.trainingData = load_csr(config['record'], target)
+            print('preprocessing...')
+            return
         columns = {}
         for col in setup['-columns'].split(','):
             name, pos = col.split(':')
             columns[name] = int(pos)
         delim = setup['-delim'] if setup.contains('-delim') else ''
 
-        if not self.config.contains('evaluation.setup'):
-            print('Evaluation is not well configured!')
-            exit(-1)
-        self.evaluation = LineConfig(config['evaluation.setup'])
         binarized = self.evaluation.contains('-b')
         bottom = float(self.evaluation['-b']) if binarized else 0
 
