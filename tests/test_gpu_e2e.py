@@ -188,8 +188,9 @@ def test_config2_through_the_driver_from_a_csr_file(tmp_path, capsys):
     measure = open(glob.glob(str(tmp_path / 'results' / '*measure*.txt'))[0]).read()
     prec10 = float(measure.split('Precision:')[1].split()[0])
     assert 0.0 < prec10 < 1.0
-    lists = open(glob.glob(str(tmp_path / 'results' / '*items*.txt'))[0]).read().splitlines()
-    assert len(lists) > 0.9 * m                                  # one line per user with held-out items
+    lists = np.load(glob.glob(str(tmp_path / 'results' / '*items*.npz'))[0])
+    assert len(lists['users']) > 0.9 * m and lists['ids'].shape == (len(lists['users']), 20)      # one list per user with held-out items
+    assert (lists['ids'] >= 0).all() and (lists['ids'] < n).all()
 
 
 def test_save_and_load_model_round_trip(tmp_path, capsys):

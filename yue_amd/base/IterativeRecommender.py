@@ -139,8 +139,9 @@ class IterativeRecommender(Recommender):
 
     def _evalRanking_arrays(self, top, N):
         """Array-native data: lists stay integer (``self.recUsers``, ``self.recIds``), the measures are
-        computed on ids (data/arrays.py: ranking_measure_ids), only the measure file is written -- a
-        lists file of concatenated numeric names would be unreadable."""
+        computed on ids (data/arrays.py: ranking_measure_ids); beside the measure file the lists go out as integer
+        arrays (``...-top-Nitems.npz``: users, ids) -- the reference's text line of concatenated names would be
+        unreadable for numeric names."""
         from os.path import abspath
         from time import localtime, strftime, time
         from ..tool.file import FileIO
@@ -153,6 +154,8 @@ class IterativeRecommender(Recommender):
         self.measure = ranking_measure_ids(d.test_indptr, d.test_indices, uids, self.recIds, top, d.getSize(self.recType))
         stamp = strftime("%Y-%m-%d %H-%M-%S", localtime(time()))
         FileIO.writeFile(self.output['-dir'], self.config['recommender'] + '@' + stamp + '-measure' + self.foldInfo + '.txt', self.measure)
+        if self.isOutput:
+            np.savez(self.output['-dir'] + self.config['recommender'] + '@' + stamp + '-top-' + str(N) + 'items' + self.foldInfo + '.npz', users=uids, ids=self.recIds)
         print('The result has been output to ', abspath(self.output['-dir']), '.')
         print('The result of %s %s:\n%s' % (self.algorName, self.foldInfo, ''.join(self.measure)))
 

@@ -738,7 +738,6 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_topn_scan: no factors uploaded");
     if (nu < 0 || (nu > 0 && (!users || !out_ids || !out_scores))) return fail(YUE_ERR_ARG, "yue_topn_scan: null argument");
     if (N < 1 || N > 100) return fail(YUE_ERR_ARG, "yue_topn_scan: N must be in 1..100");
-    if (c->k > 128) return fail(YUE_ERR_ARG, "yue_topn_scan: k > 128 is not supported by the scoring kernel yet");
     if ((mask_indptr == nullptr) != (mask_indices == nullptr)) return fail(YUE_ERR_ARG, "yue_topn_scan: pass both mask arrays or neither");
     if (!mask_indptr && !c->have_inter) return fail(YUE_ERR_ARG, "yue_topn_scan: no mask given and no interactions uploaded");
     if (nu == 0) return YUE_OK;
