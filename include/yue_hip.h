@@ -113,7 +113,7 @@ int yue_scores(yue_ctx *ctx, int32_t user, float *out_n);
  * evalRanking's selection for nu users.  Masked items per user come from mask_indptr[nu+1] /
  * mask_indices (rows sorted ascending, indexed by position in users[]); pass NULL for both to
  * mask the uploaded training items (evalRanking).  out_ids[nu*N], out_scores[nu*N], 1 <= N <= 100 (the
- * reference caps N at 100, :84-86); k <= 128.  Scores are the exact fp32 fma chain of yue_scores; for
+ * reference caps N at 100, :84-86).  Scores are the exact fp32 fma chain of yue_scores; for
  * k in {16,32,64,128} a bf16 MFMA tile pre-filters the pairs that can matter (same results).
  * Returns YUE_ERR_FEW_ITEMS if some user has fewer than N candidates (their rows are -1 / -inf).
  */

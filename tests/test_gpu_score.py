@@ -70,6 +70,8 @@ def test_lists_match_reference_golden(dev, orc, tag, N):
     (10, 97, 7, 3, 20),           # odd k (zero padded), tiny
     (70, 1500, 32, 10, 40),
     (40, 900, 48, 10, 40),        # k not in the bf16 set -> f32 kernel
+    (50, 1200, 200, 10, 30),      # k > 128 (trainable up to 256): f32 kernel with 128 k-steps
+    (20, 700, 256, 20, 30),
 ])
 def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
     P, Q, indptr, indices = _rand_problem(m, n, k, per_user, seed=m + n + k + N)

@@ -369,7 +369,7 @@ def test_degenerate_shapes(orc, m, n, k):
     nll_o = orc.bpr_sequential(Po, Qo, ev_u[ok], ev_i[ok], j[ok], 0.05, 0.01, 0.02)
     P, Q = dev.get_factors()
     assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
-    if k <= 128:
+    if k <= 256:
         mp = np.zeros(m + 1, np.int64)
         users = np.arange(m, dtype=np.int32)
         N = min(n, 3)

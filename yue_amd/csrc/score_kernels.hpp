@@ -270,108 +270,65 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 pre-filter in front of the exact path (k = 16*K16 <= 128): k_topn_scan_mx.
-//
-// |bf16 score - exact score| <= 2^-8 * sum|p_e q_e| <= 2^-8 ||P_u|| ||Q_i||, so a pair can only matter to the
-// state machine if  bf16 score + 2^-7 ||P_u|| ||Q_i|| > threshold_u  (margin doubled for slack).  Those few
-// survivors are re-scored exactly -- the same k-ascending fp32 fma chain as k_topn_scan / the oracle -- and only
-// the exact score enters the state machine: results are identical to the f32 kernel.
-//
-// Shape (one wave per SIMD, the large register file):
-//   * a wave owns U = 2 blocks of 32 users: lane (r, h) is THE lane of user r of block h -- it keeps that user's
-//     whole fp32 row in registers (the exact chain needs no memory for P), runs that user's selection state machine
-//     and its mask cursor; the bf16 rows of both blocks are the B operands of v_mfma_f32_32x32x16_bf16 and stay in
-//     registers for the whole scan.  A workgroup = 4 waves = 256 users: Q is streamed m / 256 times;
-//   * item tiles of 32 are staged ONCE per workgroup into LDS in two forms: fp32 (for the exact chains) and bf16
-//     (the A operands: one ds_read_b128 per k-step per lane, used by both blocks); tiles travel global ->
-//     registers one tile ahead -> LDS, one barrier per tile;
-//   * ITEMS are the rows of the MFMA tile and USERS its columns, so all 32 scores of user r of a block sit on lanes
-//     r and r+32: the pre-filter is 16 compares against one per-lane value, the survivor mask is assembled in-lane
-//     and completed with one exchange between the two halves of the wave;
-//   * survivors: in every phase each lane takes ITS user's next surviving item through the full k-step chain (Q row
-//     from the fp32 tile), so both halves of the wave work on different users; exact scores feed the reference's
-//     state machine (N slots in LDS) in ascending item order.  Thresholds only rise: a threshold that is one tile
-//     old only lets more pairs through.
-// U = 1 (N > 45: the N slots of 256 users no longer fit beside the tiles) keeps the upper half of the lanes idle
-// in the chains.
+// bf16 pre-filter in front of the exact path (k = 16*K16 <= 128).
+// The 32x32 tile of scores comes from v_mfma_f32_32x32x16_bf16 on bf16-rounded factors (1/16 of the
+// f32-MFMA time).  |bf16 score - exact score| <= 2^-8 * sum|p_e q_e| <= 2^-8 ||P_u|| ||Q_i||, so a
+// pair can only matter to the state machine if  bf16 score + 2^-7 ||P_u|| ||Q_i|| > threshold_u
+// (margin doubled for slack).  Those few survivors are re-scored exactly -- the same k-ascending
+// fp32 fma chain as k_topn_scan / the oracle, P row in registers, Q row from the fp32 LDS tile --
+// and only the exact score enters the state machine: results are identical to the f32 kernel.
 // ------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__host__ __device__ inline size_t scan_mx_lds_bytes(int k, int U, int NS) {
-    const size_t tiles = 2u * kScanTile * (size_t)(k + 4) * sizeof(float) + 2u * kScanTile * (size_t)(k + 8) * 2u;
-    const size_t state = (size_t)kScanWaves * 32 * U * NS * (sizeof(float) + sizeof(int32_t));
-    return tiles + state;
+__host__ __device__ inline size_t scan_bf16_lds_bytes(int k, int N) {
+    const size_t tile = 2u * kScanTile * (k + 4) * sizeof(float);
+    const size_t state = (size_t)kScanWaves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
+    return tile + state;
 }
 
-template <int K16, int U>
-__global__ void __launch_bounds__(256, 1) k_topn_scan_mx(ScanArgs a, int NS) {
+template <int K16>
+__global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int K = 16 * K16, LDF = K + 4, LDH = K + 8, UW = 32 * U;
-    const int N = a.N;
-    float *tileF = reinterpret_cast<float *>(lds_raw);                                   // [2][32][LDF] fp32
-    __bf16 *tileH = reinterpret_cast<__bf16 *>(tileF + 2 * kScanTile * LDF);             // [2][32][LDH] bf16
-    float *st_a_all = reinterpret_cast<float *>(tileH + 2 * kScanTile * LDH);            // [4][UW][NS]
-    int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + kScanWaves * UW * NS);
+    constexpr int K = 16 * K16, LD = K + 4;
+    const int N = a.N, NS = scan_ns(N);
+    float *tile = reinterpret_cast<float *>(lds_raw);                       // [2][32][LD] fp32
+    float *st_a_all = tile + 2 * kScanTile * LD;
+    int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + kScanWaves * 32 * NS);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // B fragments of both blocks: lane (r,h) supplies B[16*s + 8*h + j][user r of block b]
-    bf16x8 bfr[U][K16];
-#pragma unroll
-    for (int b = 0; b < U; ++b) {
-        const int64_t up = ((int64_t)blockIdx.x * kScanWaves + w) * UW + b * 32 + r;
-        const float *prow = a.P + (int64_t)a.users[up < a.nu ? up : 0] * K;
-#pragma unroll
-        for (int s2 = 0; s2 < K16; ++s2) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(prow + 16 * s2 + 8 * h), v1 = *reinterpret_cast<const f32x4 *>(prow + 16 * s2 + 8 * h + 4);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { bfr[b][s2][jj] = (__bf16)v0[jj]; bfr[b][s2][jj + 4] = (__bf16)v1[jj]; }
-        }
-    }
-    // my user: user r of block h (U = 1: lanes of the upper half have none)
-    const bool has_user = h < U;
-    const int64_t upos = ((int64_t)blockIdx.x * kScanWaves + w) * UW + (has_user ? h : 0) * 32 + r;
-    const bool uvalid = has_user && upos < a.nu;
+    const int64_t upos = (int64_t)blockIdx.x * (kScanWaves * 32) + w * 32 + r;
+    const bool uvalid = upos < a.nu;
     const int32_t uid = a.users[uvalid ? upos : 0];
-    float pf[K];                                                 // the exact fp32 row of my user
-    float mu_mine;
+    const float *prow = a.P + (int64_t)uid * K;
+
+    // exact fp32 row of user r for the re-score chain, split over its two lanes: lane (r,h) keeps
+    // elements [h*K/2, (h+1)*K/2).  bf16 A fragments: lane (r,h) supplies A[row r][16*s + 8*h + j].
+    constexpr int KH = K / 2;
+    float mu;                                                  // margin factor of this lane's user
+    float pf[KH];
+#pragma unroll
+    for (int e = 0; e < KH; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(prow + h * KH + e); pf[e] = v[0]; pf[e + 1] = v[1]; pf[e + 2] = v[2]; pf[e + 3] = v[3]; }
+    bf16x8 af[K16];
+#pragma unroll
+    for (int s = 0; s < K16; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) af[s][jj] = (__bf16)prow[16 * s + 8 * h + jj];
     {
-        const float *prow = a.P + (int64_t)uid * K;
         float ss = 0.0f;
 #pragma unroll
-        for (int e = 0; e < K; e += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(prow + e);
-            pf[e] = v[0]; pf[e + 1] = v[1]; pf[e + 2] = v[2]; pf[e + 3] = v[3];
-            ss = __builtin_fmaf(v[0], v[0], ss); ss = __builtin_fmaf(v[1], v[1], ss); ss = __builtin_fmaf(v[2], v[2], ss); ss = __builtin_fmaf(v[3], v[3], ss);
-        }
-        mu_mine = __builtin_sqrtf(ss) * (1.01f / 128.0f);       // 2^-7 ||P_u||, 1 % slack for the norm roundings
-    }
-    const float mu_other = __shfl_xor(mu_mine, 32);
-
-    ScanState S;
-    S.st_a = st_a_all + ((w * UW) + (has_user ? h : 0) * 32 + r) * NS; S.st_id = st_id_all + ((w * UW) + (has_user ? h : 0) * 32 + r) * NS;
-    S.cnt = 0; S.thr = -INFINITY; S.events = 0;
-    S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;
-    S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
-    int rescored = 0;
-    float thr_other = -INFINITY;                                 // threshold of the user on the other half's lane (same r)
-    int64_t mcur = 0, mend = 0;
-    int32_t mnext = 0x7fffffff;
-    if (uvalid) {
-        const int64_t mrow = a.mask_by_user ? (int64_t)uid : upos;
-        mcur = a.mask_ptr[mrow]; mend = a.mask_ptr[mrow + 1];
-        if (mcur < mend) mnext = a.mask_idx[mcur];
+        for (int e = 0; e < KH; ++e) ss = __builtin_fmaf(pf[e], pf[e], ss);
+        ss += __shfl_xor(ss, 32);
+        mu = __builtin_sqrtf(ss) * (1.01f / 128.0f);           // 2^-7 ||P_u||, 1 % slack for the norm roundings
     }
 
-    // item tiles: global -> registers (one tile ahead) -> LDS (fp32 and bf16), float4 granularity
+    // item tiles: global -> registers (one tile ahead) -> LDS, float4 granularity
     constexpr int PF4 = (kScanTile * K / 4 + 255) / 256;
-    int offF[PF4], offH[PF4];
+    int lds_off[PF4];
 #pragma unroll
-    for (int q = 0; q < PF4; ++q) { const int el = (tid + 256 * q) * 4; const int row = el / K; offF[q] = row * LDF + (el - row * K); offH[q] = row * LDH + (el - row * K); }
+    for (int q = 0; q < PF4; ++q) { const int el = (tid + 256 * q) * 4; const int row = el / K; lds_off[q] = row * LD + (el - row * K); }
     f32x4 pre[PF4];
     float nu_next = 0.0f;
     auto fetch = [&](int64_t it0) {
@@ -385,18 +342,25 @@ __global__ void __launch_bounds__(256, 1) k_topn_scan_mx(ScanArgs a, int NS) {
         nu_next = a.tile_norm_max[it0 / kScanTile];             // largest ||Q_i|| of the tile (wave-uniform)
     };
     auto commit = [&](int buf) {
-        float *dF = tileF + buf * kScanTile * LDF;
-        __bf16 *dH = tileH + buf * kScanTile * LDH;
+        float *dst = tile + buf * kScanTile * LD;
 #pragma unroll
-        for (int q = 0; q < PF4; ++q)
-            if ((tid + 256 * q) * 4 < kScanTile * K) {
-                *reinterpret_cast<f32x4 *>(dF + offF[q]) = pre[q];
-                bf16x4 hv;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) hv[jj] = (__bf16)pre[q][jj];
-                *reinterpret_cast<bf16x4 *>(dH + offH[q]) = hv;
-            }
+        for (int q = 0; q < PF4; ++q) if ((tid + 256 * q) * 4 < kScanTile * K) *reinterpret_cast<f32x4 *>(dst + lds_off[q]) = pre[q];
     };
+
+    ScanState S;
+    S.st_a = st_a_all + (w * 32 + r) * NS; S.st_id = st_id_all + (w * 32 + r) * NS;
+    S.cnt = 0; S.thr = -INFINITY; S.events = 0;
+    S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;
+    S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
+    int rescored = 0;
+    float thr_lane = -INFINITY;
+    int64_t mcur = 0, mend = 0;
+    int32_t mnext = 0x7fffffff;
+    if (h == 0 && uvalid) {
+        const int64_t mrow = a.mask_by_user ? (int64_t)uid : upos;
+        mcur = a.mask_ptr[mrow]; mend = a.mask_ptr[mrow + 1];
+        if (mcur < mend) mnext = a.mask_idx[mcur];
+    }
 
     const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
     fetch(0);
@@ -407,109 +371,85 @@ __global__ void __launch_bounds__(256, 1) k_topn_scan_mx(ScanArgs a, int NS) {
     for (int64_t t = 0; t < ntiles; ++t) {
         const int cur = (int)(t & 1);
         const int64_t it0 = t * kScanTile;
-        const float *tF = tileF + cur * kScanTile * LDF;
-        const __bf16 *tH = tileH + cur * kScanTile * LDH;
+        const float *tb = tile + cur * kScanTile * LD;
         if (t + 1 < ntiles) fetch(it0 + kScanTile);
 
-        // bf16 scores: lane (r,h) supplies A[item r][16*s + 8*h + j] and receives D[item (q&3)+8*(q>>2)+4*h][user r of block b]
-        f32x16 acc[U];
+        // bf16 scores with ITEMS as rows and USERS as columns: lane (r,h) supplies A[item r][16*s+8*h+j]
+        // from item r's fp32 row in the tile and B[16*s+8*h+j][user r] from its user's fragments, and
+        // receives D[item (q&3)+8*(q>>2)+4*h][user r]: all 32 scores of user r sit on lanes r and r+32.
+        f32x16 acc;
 #pragma unroll
-        for (int b = 0; b < U; ++b)
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        const float *irow = tb + r * LD + 8 * h;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[b][q] = 0.0f;
-        const __bf16 *irow = tH + r * LDH + 8 * h;
+        for (int s = 0; s < K16; ++s) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(irow + 16 * s), b1 = *reinterpret_cast<const f32x4 *>(irow + 16 * s + 4);
+            bf16x8 itf;
 #pragma unroll
-        for (int s2 = 0; s2 < K16; ++s2) {
-            const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s2);
-#pragma unroll
-            for (int b = 0; b < U; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, bfr[b][s2], acc[b], 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj) { itf[jj] = (__bf16)b0[jj]; itf[jj + 4] = (__bf16)b1[jj]; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[s], acc, 0, 0, 0);
         }
 
-        // pre-filter in registers: block b's user r is filtered with the threshold its own lane (r, b) keeps.
-        // First only the largest of a lane's 16 scores per block is looked at: in most tiles nothing passes anywhere.
-        float bar[U];
-        bool some = false;
+        // pre-filter in registers: the user's threshold minus the margin is one per-lane value
+        const float bar = thr_lane - mu * nu;
+        uint32_t pmask = 0u;
 #pragma unroll
-        for (int b = 0; b < U; ++b) {
-            bar[b] = (b == h ? S.thr : thr_other) - (b == h ? mu_mine : mu_other) * nu;
-            float mx = __builtin_fmaxf(acc[b][0], acc[b][1]);
-#pragma unroll
-            for (int q = 2; q < 16; q += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(acc[b][q], acc[b][q + 1]));
-            some = some || bar[b] < mx;
-        }
-        uint32_t mymask = 0u;
-        if (__ballot(some) != 0ull) {
-#pragma unroll
-            for (int b = 0; b < U; ++b) {
-                uint32_t pmask = 0u;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pmask |= (bar[b] < acc[b][q] ? 1u : 0u) << ((q & 3) + 8 * (q >> 2));
-                pmask <<= 4 * h;                                   // rows of lane (r,1) are shifted by 4
-                pmask |= (uint32_t)__shfl_xor((int)pmask, 32);     // both lanes now hold all 32 items of user (b, r)
-                if (b == h) mymask = pmask;
-            }
-        }
+        for (int q = 0; q < 16; ++q) pmask |= (bar < acc[q] ? 1u : 0u) << ((q & 3) + 8 * (q >> 2));
+        pmask <<= 4 * h;                                       // rows of lane (r,1) are shifted by 4
+        pmask |= (uint32_t)__shfl_xor((int)pmask, 32);         // both lanes of a user now hold all 32 columns
         const int64_t left = a.n - it0;
-        if (left < kScanTile) mymask &= (1u << (uint32_t)left) - 1u;
+        if (left < kScanTile) pmask &= (1u << (uint32_t)left) - 1u;
+
         uint32_t cand = 0u;
-        if (uvalid) {
+        if (h == 0 && uvalid) {
             uint32_t mb = 0u;
             while (mnext < it0 + kScanTile) {
                 mb |= 1u << (uint32_t)(mnext - it0);
                 ++mcur;
                 mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
             }
-            cand = mymask & ~mb;
+            cand = pmask & ~mb;
         }
-        // survivors: one phase = every lane takes its user's next TWO surviving items through the exact chain
-        // (k-ascending fp32 fma chain == v_mfma_f32_32x32x2_f32 == oracle) -- two independent chains keep the fma
-        // pipe busy where one would wait for itself -- then feeds them, in ascending item order, through the state
-        // machine.  A slot without a survivor runs on row 0 and is dropped.
-        while (__ballot(cand != 0u) != 0ull) {
-            int c[2];
-            bool v[2];
+        // Survivors.  Exact score = k-ascending fp32 fma chain (== v_mfma_f32_32x32x2_f32, == oracle),
+        // run as a two-stage pipeline over the user's two lanes: in every phase lane (r,0) takes the
+        // user's next survivor through elements [0,K/2) while lane (r,1) finishes the previous one
+        // through [K/2,K) from the partial handed over -- one chain execution per phase for the whole
+        // wave, survivors complete in ascending item order.
+        int c_prev = -1;
+        float s_prev = 0.0f;
+        for (;;) {
+            const int c_pop = (h == 0 && cand) ? __ffs(cand) - 1 : -1;
+            const int c_from = __shfl(c_prev, r);
+            const float s_from = __shfl(s_prev, r);
+            const int c_cur = h ? c_from : c_pop;
+            float sc = h ? s_from : 0.0f;
+            if (__ballot(c_cur >= 0) == 0ull) break;
+            if (c_pop >= 0) cand &= cand - 1;
+            if (c_cur >= 0) {
+                const float *qrow = tb + c_cur * LD + h * KH;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                v[s2] = cand != 0u;
-                c[s2] = v[s2] ? __ffs(cand) - 1 : 0;
-                cand &= cand - 1u;                               // 0 stays 0
-            }
-            const float *q0 = tF + c[0] * LDF, *q1 = tF + c[1] * LDF;
-            float sc[2] = {0.0f, 0.0f};
-            // 8 elements per step; the reads of step i+1 are issued before the 16 fmas of step i
-            f32x4 x0[2][2], x1[2][2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) { x0[0][g] = *reinterpret_cast<const f32x4 *>(q0 + 4 * g); x1[0][g] = *reinterpret_cast<const f32x4 *>(q1 + 4 * g); }
-#pragma unroll
-            for (int st = 0; st < K / 8; ++st) {
-                const int cb = st & 1, nb = cb ^ 1;
-                if (st + 1 < K / 8) {
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) { x0[nb][g] = *reinterpret_cast<const f32x4 *>(q0 + 8 * (st + 1) + 4 * g); x1[nb][g] = *reinterpret_cast<const f32x4 *>(q1 + 8 * (st + 1) + 4 * g); }
+                for (int e = 0; e < KH; e += 4) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
+                    sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
+                    sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
                 }
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        sc[0] = __builtin_fmaf(pf[8 * st + 4 * g + jj], x0[cb][g][jj], sc[0]);
-                        sc[1] = __builtin_fmaf(pf[8 * st + 4 * g + jj], x1[cb][g][jj], sc[1]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                if (v[s2]) {
-                    ++rescored;
-                    if (!(S.cnt == N && !(S.thr < sc[s2]))) scan_push(S, N, sc[s2], (int32_t)(it0 + c[s2]), a.true_topn);
-                }
+            const float s_done = __shfl(sc, r + 32);          // finished scores travel back to lane (r,0)
+            const int c_done = __shfl(c_cur, r + 32);
+            if (h == 0 && c_done >= 0) {
+                ++rescored;
+                if (!(S.cnt == N && !(S.thr < s_done))) scan_push(S, N, s_done, (int32_t)(it0 + c_done), a.true_topn);
+            }
+            c_prev = c_cur;
+            s_prev = sc;
         }
-        thr_other = __shfl_xor(S.thr, 32);
+        thr_lane = __shfl(S.thr, r);                           // lane (r,1) filters with its user's threshold too
         if (t + 1 < ntiles) commit(cur ^ 1);
         nu = nu_next;
         __syncthreads();
     }
 
-    if (uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
 }
 
 template <int K2>
@@ -517,37 +457,31 @@ inline void launch_scan_f32(const ScanArgs &a, hipStream_t stream, dim3 grid, si
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<K2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_topn_scan<K2>, grid, dim3(256), lds, stream, a);
 }
-template <int K16, int U>
-inline void launch_scan_mx(const ScanArgs &a, hipStream_t stream, int NS) {
-    const size_t lds = scan_mx_lds_bytes(16 * K16, U, NS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan_mx<K16, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 grid((unsigned)((a.nu + kScanWaves * 32 * U - 1) / (kScanWaves * 32 * U)));
-    hipLaunchKernelGGL((k_topn_scan_mx<K16, U>), grid, dim3(256), lds, stream, a, NS);
-}
 template <int K16>
-inline void launch_scan_mx_u(const ScanArgs &a, hipStream_t stream) {
-    // 256 users per workgroup while their N slots fit beside the tiles in the 160 KB of LDS (N <= 45), else 128
-    if (a.N <= 45) launch_scan_mx<K16, 2>(a, stream, scan_ns(a.N));
-    else launch_scan_mx<K16, 1>(a, stream, scan_ns(a.N));
+inline void launch_scan_bf16(const ScanArgs &a, hipStream_t stream, dim3 grid, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan_bf16<K16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_topn_scan_bf16<K16>, grid, dim3(256), lds, stream, a);
 }
 
 // force_f32 != 0: always the exact-f32-MFMA kernel.  Otherwise k in {16,32,64,128} takes the bf16
 // pre-filter kernel (identical results), anything else the f32 kernel.  Returns 1 if bf16 was used.
 inline int launch_scan(const ScanArgs &a, hipStream_t stream, int force_f32) {
     if (a.k > 256 || a.N > 100) return -1;
+    const dim3 grid((unsigned)((a.nu + kScanWaves * 32 - 1) / (kScanWaves * 32)));
     if (!force_f32 && (a.k == 16 || a.k == 32 || a.k == 64 || a.k == 128)) {
+        const size_t lds = scan_bf16_lds_bytes(a.k, a.N);
         switch (a.k) {
-            case 16: launch_scan_mx_u<1>(a, stream); break;
-            case 32: launch_scan_mx_u<2>(a, stream); break;
-            case 64: launch_scan_mx_u<4>(a, stream); break;
-            default: launch_scan_mx_u<8>(a, stream); break;
+            case 16: launch_scan_bf16<1>(a, stream, grid, lds); break;
+            case 32: launch_scan_bf16<2>(a, stream, grid, lds); break;
+            case 64: launch_scan_bf16<4>(a, stream, grid, lds); break;
+            default: launch_scan_bf16<8>(a, stream, grid, lds); break;
         }
         return 1;
     }
-    const dim3 grid((unsigned)((a.nu + kScanWaves * 32 - 1) / (kScanWaves * 32)));
     const int kp = a.k + (a.k & 1);
-    const int K2 = kp / 2 <= 8 ? 8 : kp / 2 <= 16 ? 16 : kp / 2 <= 32 ? 32 : kp / 2 <= 64 ? 64 : 128;
+    const int K2 = kp / 2 <= 8 ? 8 : kp / 2 <= 16 ? 16 : kp / 2 <= 32 ? 32 : kp / 2 <= 64 ? 64 : 128;      // k <= 256, as the training kernels
     const size_t lds = scan_lds_bytes(K2, a.N);
+    if (lds > 160u * 1024u) return -1;                     // 128 < k <= 256 together with N > 66: the N slots of 128 users no longer fit beside the tiles
     switch (K2) {
         case 8: launch_scan_f32<8>(a, stream, grid, lds); break;
         case 16: launch_scan_f32<16>(a, stream, grid, lds); break;

@@ -773,7 +773,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipEventRecord(t0, c->stream));
     int rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32);
     HIPCHK(hipEventRecord(t1, c->stream));
-    if (rc < 0) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination");
+    if (rc < 0) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination (k <= 256; for k > 128 the list length N is limited to 66)");
     c->scan_used_bf16 = rc;
     HIPCHK(hipGetLastError());
     int32_t flags[4];
