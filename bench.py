@@ -43,8 +43,8 @@ WORKLOADS = {
     # scoring (BASELINE config 5): all users x all items, top-20 selection, training items masked
     'c5': (1000000, 200000, 50, 128),
     'c5small': (65536, 200000, 50, 128),
-    # FISM parity path: the reference's sequential epoch, FISM.conf's k and rho on a BPR.conf-sized log
-    'fism': (1000, 1000, 20, 10),
+    # FISM: the round form on a 100K-user problem, FISM.conf's rho / alpha / learning rate
+    'fism': (100000, 20000, 20, 64),
 }
 MFMA_F32_PEAK = 157.3e12   # dense f32-input MFMA, MI355X (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK = 2.5e15    # dense bf16 MFMA
@@ -220,10 +220,12 @@ def bench_scoring(args, cp):
 
 
 def bench_fism(args, cp):
-    """Extra line for the FISM parity path: draws/s of the sequential device epoch (one wave by construction)
-    beside the reference's loop as NumPy runs it (oracle/numpy_fism.py).  Not the headline metric."""
+    """Extra line for FISM: draws/s of the round form (yue_fism_rounds, one wave per user, the users of a
+    round at once) on a 100K-user problem, beside the sequential device pass (one wave by construction, the reference's exact
+    order) and the reference's loop as NumPy runs it (oracle/numpy_fism.py) on samples of the same workload.  Not the headline."""
     m, n, d, k = WORKLOADS['fism']
     rho, alpha, lr, reg = 2, 0.5, 0.015, 0.01                      # the reference's FISM.conf
+    round_users = args.round_events if args.round_events > 0 else 256     # larger rounds diverge on this problem (sums of stale differences on the popular items)
     data = synth.make_arrays(m, n, d, seed=20260001)
     rs = np.random.RandomState(20260005)
     Q0 = (rs.rand(n, k).astype(np.float32) / 10)
@@ -232,50 +234,57 @@ def bench_fism(args, cp):
     draws = int(np.diff(ptr)[np.diff(ptr) > 1].sum()) * rho
 
     def negatives(epoch):
+        # rejection against the user's items (FISM.py:50-53), vectorised: redraw the hits
         g = np.random.RandomState(77 + epoch)
-        out = np.empty(draws, np.int32)
-        pos = 0
-        for u in range(m):
-            nu = int(ptr[u + 1] - ptr[u])
-            if nu <= 1:
-                continue
-            mine = set(ev_i[ptr[u]:ptr[u + 1]].tolist())
-            for _ in range(nu * rho):
-                j = int(g.randint(n))
-                while j in mine:
-                    j = int(g.randint(n))
-                out[pos] = j
-                pos += 1
-        return out
+        ev_u = np.repeat(np.arange(m, dtype=np.int64), np.diff(ptr))
+        uu = np.repeat(ev_u, rho)
+        out = g.randint(0, n, size=len(uu)).astype(np.int64)
+        keys = np.unique(ev_u * n + ev_i)
+        while True:
+            bad = np.isin(uu * n + out, keys)
+            if not bad.any():
+                break
+            out[bad] = g.randint(0, n, size=int(bad.sum()))
+        return out.astype(np.int32)
     negs = [negatives(e) for e in range(args.warmup + args.steps)]
     coef = np.array([pow(int(x) - 1, -alpha) if x > 1 else 0.0 for x in np.diff(ptr)], np.float64)
     dev = Device(cp.local_rank, raise_errors=True)
     dev.fism_set_model(P0, Q0, B0)
     for e in range(args.warmup):
-        dev.fism_epoch(ptr, ev_i, negs[e], rho, coef, lr, reg, reg)
+        dev.fism_rounds(ptr, ev_i, negs[e], rho, coef, round_users, lr, reg, reg)
     t0 = time.perf_counter()
     for e in range(args.warmup, args.warmup + args.steps):
-        half = dev.fism_epoch(ptr, ev_i, negs[e], rho, coef, lr, reg, reg)[0]
+        half = dev.fism_rounds(ptr, ev_i, negs[e], rho, coef, round_users, lr, reg, reg)[0]
     dt = time.perf_counter() - t0
+    # the sequential device pass and the NumPy loop on the first users of the same problem
+    su = min(m, 2000)
+    sl = slice(0, int(ptr[su]))
+    nsl = slice(0, int(np.diff(ptr[:su + 1])[np.diff(ptr[:su + 1]) > 1].sum()) * rho)
+    dev.fism_set_model(P0, Q0, B0)
+    t1 = time.perf_counter()
+    dev.fism_epoch(ptr[:su + 1], ev_i[sl], negs[0][nsl], rho, coef[:su], lr, reg, reg)
+    seq_dt = time.perf_counter() - t1
     cpu = None
     if not args.no_cpu_baseline:
         from oracle.numpy_fism import fism_epoch
         P, Q, Bi = P0.copy(), Q0.copy(), B0.copy()
         t1 = time.perf_counter()
-        fism_epoch(P, Q, Bi, ptr, ev_i, negs[0], rho, alpha, lr, reg, reg)
+        fism_epoch(P, Q, Bi, ptr[:su + 1], ev_i[sl], negs[0][nsl], rho, alpha, lr, reg, reg)
         cdt = time.perf_counter() - t1
-        cpu = {'value': draws / cdt, 'unit': 'draws/s', 'cores': 1, 'kind': 'port',
-               'sample': 'one epoch of the same workload, oracle/numpy_fism.py (the NumPy statements of recommender/cf/FISM.py:38-69, bit-equal to the reference on its goldens), %.1f s on %s' % (cdt, _cpu_name())}
+        cpu = {'value': (nsl.stop - nsl.start) / cdt, 'unit': 'draws/s', 'cores': 1, 'kind': 'port',
+               'sample': 'the first %d users of the same workload, oracle/numpy_fism.py (the NumPy statements of recommender/cf/FISM.py:38-69, bit-equal to the reference on its goldens), %.1f s on %s' % (su, cdt, _cpu_name())}
     bytes_per_draw = 32 * k + 32                                    # P[i], P[j] read (f64), Q[i], Q[j] read + written (f32), four bias accesses
     ach = bytes_per_draw * draws * args.steps / dt
     print(json.dumps({
-        'metric': 'FISM draw-updates/sec, sequential parity path, k=%d' % k, 'value': draws * args.steps / dt, 'unit': 'draws/s', 'n_gpus': 1,
+        'metric': 'FISM draw-updates/sec, rounds of %d users, k=%d' % (round_users, k), 'value': draws * args.steps / dt, 'unit': 'draws/s', 'n_gpus': 1,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64 (P, Bi) / f32 (Q)', 'data': 'synthetic',
-        'config': {'workload': 'FISM: %d users x %d items, %d events/user, k=%d, rho=%d, alpha=%g, lr=%g, reg=%g; host upload of events and negatives included in value'
-                               % (m, n, d, k, rho, alpha, lr, reg), 'final_half_sq_error': half},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_fism_epoch<KR=1> (one wave: the reference order is one dependency chain)', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
-                     'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'algorithmic_bytes_per_draw': bytes_per_draw, 'traffic': None},
+        'config': {'workload': 'FISM: %d users x %d items, %d events/user, k=%d, rho=%d, alpha=%g, lr=%g, reg=%g, rounds of %d users; host work of a call '
+                               '(touched-item lists per user, upload of events and negatives) included in value' % (m, n, d, k, rho, alpha, lr, reg, round_users),
+                   'final_half_sq_error': half,
+                   'sequential_device_pass_draws_per_s': (nsl.stop - nsl.start) / seq_dt},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_fism_round<KR=%d> (one wave per user: latency of the user\'s chain of draws)' % (1 if k <= 64 else 2 if k <= 128 else 4),
+                     'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'algorithmic_bytes_per_draw': bytes_per_draw, 'traffic': None},
         'cpu_baseline': cpu}))
     dev.close()
     cp.close()

@@ -151,6 +151,11 @@ int yue_set_option(yue_ctx *ctx, const char *name, int64_t value);
  *                    with one event skipped; negs = the accepted negatives in processing order (rho per event,
  *                    drawn by the caller as FISM.py:50-53 does); coef[u] = pow(nu - 1, -alpha) (FISM.py:42).
  *                    Outputs: sum of 0.5*error^2 (:58) and {sum(P*P), sum(Q*Q), Bi.Bi} after the pass (:70).
+ *   yue_fism_rounds  the throughput form of the same pass (ours; DESIGN.md section 10, oracle/numpy_fism.py: fism_rounds):
+ *                    rounds of round_users consecutive users; every user of a round runs the reference's whole per-user
+ *                    loop on the model as it was when the round started plus its own changes, the per-row differences of
+ *                    the round's users are summed and added once.  round_users = 1 is yue_fism_epoch.  Same arguments
+ *                    and outputs otherwise.
  *   yue_fism_scores  replaces FISM.predict (FISM.py:75-83) for a user whose training events are `items`.
  *   yue_fism_topn_scan  predict + the selection of base/IterativeRecommender.py:98-145 for nu users given as a
  *                    CSR of their training events (mask = those items).  YUE_ERR_FEW_ITEMS as yue_topn_scan.
@@ -159,6 +164,8 @@ int yue_fism_set_model(yue_ctx *ctx, const double *P, const float *Q, const doub
 int yue_fism_get_model(yue_ctx *ctx, double *P, float *Q, double *Bi);
 int yue_fism_epoch(yue_ctx *ctx, const int64_t *user_ptr, int64_t m, const int32_t *ev_i, const int32_t *negs, int64_t n_negs, int rho,
                    const double *coef, double lr, double regI, double regB, double *half_sq_out, double *sumsq3_out);
+int yue_fism_rounds(yue_ctx *ctx, const int64_t *user_ptr, int64_t m, const int32_t *ev_i, const int32_t *negs, int64_t n_negs, int rho,
+                    const double *coef, int64_t round_users, double lr, double regI, double regB, double *half_sq_out, double *sumsq3_out);
 int yue_fism_scores(yue_ctx *ctx, const int32_t *items, int64_t n_items, double *out_n);
 int yue_fism_topn_scan(yue_ctx *ctx, const int64_t *row_ptr, const int32_t *row_items, int64_t nu, int N, int32_t *out_ids, double *out_scores);
 

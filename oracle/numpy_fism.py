@@ -83,3 +83,31 @@ def overwrite_scan(scores, masked, N):
                 p += 1
             vals[p], ids[p] = s, t
     return ids, vals
+
+
+def fism_rounds(P, Q, Bi, user_ptr, ev_i, negs, rho, alpha, lRate, regI, regB, round_users):
+    """Round semantics of the throughput path (ours): the users are cut into consecutive rounds of
+    `round_users` users.  Inside a round every user runs the reference's whole per-user loop (FISM.py:39-68, draws and
+    item-history updates in order) on the model AS IT WAS WHEN THE ROUND STARTED plus the user's own changes so far;
+    per row the differences (user's final row - round-start row) are summed over the round's users and added once.
+    Rounds are applied in order.  One user per round is the reference loop up to x + (x' - x) rounding.
+    In place on P, Q, Bi; returns the sum of 0.5*error**2."""
+    assert P.dtype == np.float64 and Q.dtype == np.float32 and Bi.dtype == np.float64
+    m = len(user_ptr) - 1
+    nus = np.diff(user_ptr)
+    neg_ptr = np.concatenate([[0], np.cumsum(np.where(nus > 1, nus * rho, 0))])
+    half_sq = 0
+    for u0 in range(0, m, round_users):
+        u1 = min(m, u0 + round_users)
+        dP, dQ, dB = np.zeros_like(P), np.zeros_like(Q), np.zeros_like(Bi)
+        for u in range(u0, u1):
+            Pw, Qw, Bw = P.copy(), Q.copy(), Bi.copy()           # the user's private view (small problems only: this is the checker)
+            half_sq += fism_epoch(Pw, Qw, Bw, np.array([0, nus[u]]), ev_i[user_ptr[u]:user_ptr[u + 1]], negs[neg_ptr[u]:neg_ptr[u + 1]],
+                                  rho, alpha, lRate, regI, regB)
+            dP += Pw - P
+            dQ += Qw - Q
+            dB += Bw - Bi
+        P += dP
+        Q += dQ
+        Bi += dB
+    return half_sq

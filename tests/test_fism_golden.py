@@ -69,3 +69,24 @@ def test_fism_negatives_follow_the_draw_log():
                 j = next(it)
             got.append(j)
     assert got == z['negs'].tolist() and next(it, None) is None
+
+
+def test_rounds_of_one_user_are_the_reference_pass():
+    # oracle/numpy_fism.py: fism_rounds with one user per round against the reference's own output (pins the round oracle)
+    from oracle.numpy_fism import fism_rounds
+    z, meta, ptr = fism_case('fism_c1_k10_e2')
+    iters, rho, alpha = int(z['iters']), int(z['rho']), float(z['alpha'])
+    P, Q, Bi = z['P0'].copy(), z['Q0'].copy(), z['B0'].copy()
+    per = len(z['negs']) // iters
+    half = fism_rounds(P, Q, Bi, ptr, z['ev_i'], z['negs'][:per], rho, alpha, LR0, REG, REG, 1)
+    from oracle.numpy_fism import fism_epoch
+    Pe, Qe, Be = z['P0'].copy(), z['Q0'].copy(), z['B0'].copy()
+    half_e = fism_epoch(Pe, Qe, Be, ptr, z['ev_i'], z['negs'][:per], rho, alpha, LR0, REG, REG)
+    # x + (x' - x) may differ from x' in the last float32 bit of a Q element; what later users read from it moves the
+    # float64 arrays by as much
+    assert np.abs(P - Pe).max() <= 1e-6 * np.abs(Pe).max() and np.abs(Bi - Be).max() <= 1e-6 * np.abs(Be).max()
+    assert np.abs(Q - Qe).max() <= 1e-6 * np.abs(Qe).max() and abs(half - half_e) <= 1e-6 * half_e
+    # larger rounds move away from the sequential pass, but only slightly on this data
+    P8, Q8, B8 = z['P0'].copy(), z['Q0'].copy(), z['B0'].copy()
+    half8 = fism_rounds(P8, Q8, B8, ptr, z['ev_i'], z['negs'][:per], rho, alpha, LR0, REG, REG, 8)
+    assert abs(half8 - half_e) < 0.02 * half_e and np.abs(Q8 - Qe).max() > 0

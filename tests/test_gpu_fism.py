@@ -94,6 +94,53 @@ def test_against_the_numpy_oracle_on_other_inputs(dev):
         dev.fism_epoch(ptr, ev_i, negs[:-1], rho, coefs(ptr, alpha), 0.02, 0.01, 0.03)
 
 
+@pytest.mark.parametrize('tag,round_users', [('fism_c1_k10_e2', 1), ('fism_c1_k10_e2', 16), ('fism_d2_k64_e1', 64), ('fism_d3_k130_e3', 1000)])
+def test_rounds_match_the_numpy_oracle(dev, tag, round_users):
+    # throughput form: rounds of users (k_fism_round, one wave per user) against oracle/numpy_fism.py: fism_rounds;
+    # one user per round also against the reference's own result
+    from oracle.numpy_fism import fism_rounds
+    z, meta, ptr = fism_case(tag)
+    iters, rho, alpha = int(z['iters']), int(z['rho']), float(z['alpha'])
+    per = len(z['negs']) // iters
+    dev.fism_set_model(z['P0'], z['Q0'], z['B0'])
+    half, sp, sq, sb = dev.fism_rounds(ptr, z['ev_i'], z['negs'][:per], rho, coefs(ptr, alpha), round_users, LR0, REG, REG)
+    Po, Qo, Bo = z['P0'].copy(), z['Q0'].copy(), z['B0'].copy()
+    half_o = fism_rounds(Po, Qo, Bo, ptr, z['ev_i'], z['negs'][:per], rho, alpha, LR0, REG, REG, round_users)
+    P, Q, Bi = np.empty_like(Po), np.empty_like(Qo), np.empty_like(Bo)
+    dev.fism_get_model(P, Q, Bi)
+    # the float32 sums of a round's differences come in atomic order: Q within float32 rounding, and the float64 arrays
+    # that later users compute from Q move by as much
+    assert rel_err(P, Po) < 1e-6 and rel_err(Bi, Bo) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(half - half_o) < 1e-6 * half_o
+    assert abs(sp - (P * P).sum()) < 1e-10 * sp and abs(sb - Bi.dot(Bi)) < 1e-10 * sb
+    if round_users == 1 and iters == 1:
+        assert rel_err(P, z['P']) < 1e-6 and rel_err(Q, z['Q']) < 1e-6         # one user per round: the reference's pass
+
+
+def test_rounds_on_ragged_users_with_repeats(dev):
+    # users without / with one event, duplicates inside a user, negatives that repeat, k = 200 (four registers per lane and row)
+    from oracle.numpy_fism import fism_rounds
+    rng = np.random.RandomState(7)
+    n, k, rho, alpha = 60, 200, 3, 0.6
+    sizes = [0, 1, 5, 12, 1, 30, 2, 0, 7, 9, 3]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev_i = np.concatenate([rng.randint(0, n // 2, s) for s in sizes]).astype(np.int32)
+    negs = []
+    for u, s in enumerate(sizes):
+        if s > 1:
+            mine = set(ev_i[ptr[u]:ptr[u + 1]].tolist())
+            negs += [int(rng.choice([x for x in range(n) if x not in mine])) for _ in range(s * rho)]
+    negs = np.array(negs, np.int32)
+    P0, Q0, B0 = rng.rand(n, k) / 100, (rng.rand(n, k) / 10).astype(np.float32), rng.rand(n) / 100
+    for round_users in (1, 4, 100):
+        dev.fism_set_model(P0, Q0, B0)
+        half, _, _, _ = dev.fism_rounds(ptr, ev_i, negs, rho, coefs(ptr, alpha), round_users, 0.02, 0.01, 0.03)
+        Po, Qo, Bo = P0.copy(), Q0.copy(), B0.copy()
+        half_o = fism_rounds(Po, Qo, Bo, ptr, ev_i, negs, rho, alpha, 0.02, 0.01, 0.03, round_users)
+        P, Q, Bi = np.empty_like(P0), np.empty_like(Q0), np.empty_like(B0)
+        dev.fism_get_model(P, Q, Bi)
+        assert rel_err(P, Po) < 1e-6 and rel_err(Bi, Bo) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(half - half_o) < 1e-6 * half_o, round_users
+
+
 def test_through_the_plugin_surface(tmp_path, capsys):
     # FISM.conf keys on the C1 log, driven as tools/make_goldens.py drives the reference's class
     from yue_amd import synth

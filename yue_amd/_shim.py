@@ -24,7 +24,7 @@ SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy',
            'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
            'yue_default_round_events', 'yue_epoch_plan',
-           'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_scores', 'yue_fism_topn_scan']
+           'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_rounds', 'yue_fism_scores', 'yue_fism_topn_scan']
 
 
 class YueHipError(RuntimeError):
@@ -262,6 +262,19 @@ class Device(object):
         sums = (C.c_double * 3)()
         self._chk(self._lib.yue_fism_epoch(self._ctx, a, C.c_int64(len(user_ptr) - 1), b, c, C.c_int64(n_negs), C.c_int(rho), d,
                                            C.c_double(lr), C.c_double(regI), C.c_double(regB), C.byref(half), sums))
+        return half.value, sums[0], sums[1], sums[2]
+
+    def fism_rounds(self, user_ptr, ev_i, negs, rho, coef, round_users, lr, regI, regB):
+        """The same pass in rounds of `round_users` users (throughput form).  Returns (sum of 0.5*error^2, sum(P*P), sum(Q*Q), Bi.Bi)."""
+        user_ptr, a = _i64(user_ptr)
+        ev_i, b = _i32(ev_i if len(ev_i) else np.zeros(1, np.int32))
+        n_negs = len(negs)
+        negs, c = _i32(negs if n_negs else np.zeros(1, np.int32))
+        coef, d = _f64(coef)
+        half = C.c_double()
+        sums = (C.c_double * 3)()
+        self._chk(self._lib.yue_fism_rounds(self._ctx, a, C.c_int64(len(user_ptr) - 1), b, c, C.c_int64(n_negs), C.c_int(rho), d, C.c_int64(round_users),
+                                            C.c_double(lr), C.c_double(regI), C.c_double(regB), C.byref(half), sums))
         return half.value, sums[0], sums[1], sums[2]
 
     def fism_scores(self, items):

@@ -4,8 +4,8 @@
 // Q[i], Q[j], Bi[i], Bi[j] in place, the next draw reads them, and the user's item-history rows P[.]
 // are rewritten when the user is done (FISM.py:38-69).  Users share items, so the dependency chain runs
 // through the whole epoch: k_fism_epoch is ONE wave that walks the epoch in the reference's order
-// (lane l holds elements 64r + l of a row).  It exists to reproduce the reference, not to be fast; a
-// round-based throughput version (as k_round is for BPR) is the next step for this model.
+// (lane l holds elements 64r + l of a row).  It exists to reproduce the reference, not to be fast; the
+// throughput version is k_fism_round below (rounds of users, one wave per user).
 //
 // Types as the reference leaves them: P float64 [n,k] (item-history factors), Q float32 [n,k],
 // Bi float64 [n].  Arithmetic follows the NumPy expressions term by term (python-float coefficients,
@@ -131,6 +131,159 @@ __global__ void __launch_bounds__(64) k_fism_epoch(FismArgs a) {
         }
     }
     if (lane == 0) a.out[0] = half_sq;
+}
+
+// ------------------------------------------------------------------------------------------
+// Throughput path: rounds of users (oracle/numpy_fism.py: fism_rounds).
+// Every user of a round runs the reference's whole per-user loop -- draws and item-history updates in the reference's
+// order, on the model as it was when the round started plus the user's OWN changes so far -- in a private working
+// copy of the rows it touches (its events' items and its negatives; the host hands over, per user, the list of those
+// items and, per event / draw, the position of its item in that list).  One wave per user, all users of the round at
+// once.  At the end the wave adds (working row - round-start row) into the difference buffers with atomics;
+// k_fism_apply adds the sums to the model once per round.  One user per round reproduces k_fism_epoch.
+// ------------------------------------------------------------------------------------------
+struct FismRoundArgs {
+    int64_t u_begin, u_end;          // users of this round
+    const int64_t *uq_ptr;           // [m+1] touched items of user u: uq_items[uq_ptr[u] : uq_ptr[u+1]] (ascending, unique)
+    const int32_t *uq_items;
+    const int32_t *loc_i;            // [E] position of the event's item in its user's list
+    const int32_t *loc_j;            // [n_negs] position of the draw's negative in its user's list
+    const int64_t *neg_ptr;          // [m+1] first draw of user u in negs / loc_j
+    int64_t w_base;                  // first working row of the round (= uq_ptr[u_begin]); x_base likewise for events
+    float *wq;                       // working copies [rows of the round][k]
+    double *wp, *wb;                 // [rows][k], [rows]
+    float *dQ;                       // difference buffers [n,k], [n,k], [n]
+    double *dP, *dB;
+};
+
+template <int KR>
+__global__ void __launch_bounds__(256) k_fism_round(FismArgs a, FismRoundArgs ra) {
+    const int lane = threadIdx.x & 63;
+    const int64_t u = ra.u_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= ra.u_end) return;
+    const int k = a.k;
+    const int64_t e0 = a.user_ptr[u], e1 = a.user_ptr[u + 1];
+    if (e1 - e0 <= 1) return;                            // FISM.py:40-41
+    const float regI32 = (float)a.regI;
+    const int64_t q0 = ra.uq_ptr[u], q1 = ra.uq_ptr[u + 1];
+    const int64_t wrow0 = q0 - ra.w_base;                // my first working row
+    float *wq = ra.wq + wrow0 * k;
+    double *wp = ra.wp + wrow0 * k, *wb = ra.wb + wrow0;
+    double *xr = a.x_rows + (e0 - a.user_ptr[ra.u_begin]) * k;
+    // copy in the rows this user touches
+    for (int64_t s = 0; s < q1 - q0; ++s) {
+        const int64_t it = ra.uq_items[q0 + s];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int el = 64 * r + lane;
+            if (el < k) { stg_f32(wq + s * k + el, a.Q[it * k + el]); stg_f64(wp + s * k + el, a.P[it * k + el]); }
+        }
+        if (lane == 0) stg_f64(wb + s, a.Bi[it]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const double coef = a.coef[u];
+    double hist[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) hist[r] = 0.0;
+    for (int64_t e = e0; e < e1; ++e) {                  // :44-46
+        const int64_t s = ra.loc_i[e];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) hist[r] = hist[r] + ldg_f64(wp + s * k + el); }
+    }
+    double half_sq = 0.0;
+    int64_t cursor = ra.neg_ptr[u];
+    for (int64_t e = e0; e < e1; ++e) {
+        const int64_t i = ra.loc_i[e];
+        double x[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) x[r] = 0.0;
+        for (int c = 0; c < a.rho; ++c) {
+            const int64_t j = ra.loc_j[cursor++];
+            double di[KR], dj[KR];
+            float qi[KR], qj[KR];
+            double ai = 0.0, aj = 0.0;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int el = 64 * r + lane;
+                di[r] = dj[r] = 0.0; qi[r] = qj[r] = 0.0f;
+                if (el < k) {
+                    di[r] = hist[r] - ldg_f64(wp + i * k + el);
+                    dj[r] = hist[r] - ldg_f64(wp + j * k + el);
+                    qi[r] = ldg_f32(wq + i * k + el);
+                    qj[r] = ldg_f32(wq + j * k + el);
+                }
+                const double m1 = di[r] * (double)qi[r]; ai = ai + m1;
+                const double m2 = dj[r] * (double)qj[r]; aj = aj + m2;
+            }
+            const double bi = ldg_f64(wb + i), bj = ldg_f64(wb + j);
+            const double r_pos = coef * wave_sum_f64(ai) + bi;          // :54
+            const double r_neg = coef * wave_sum_f64(aj) + bj;          // :55
+            const double err = 1.0 - (r_pos - r_neg);
+            half_sq = half_sq + 0.5 * (err * err);                      // :58
+            if (lane == 0) {
+                stg_f64(wb + i, bi + a.lr * (err - a.regB * bi));       // :59
+                stg_f64(wb + j, bj - a.lr * (err + a.regB * bj));       // :60
+            }
+            const double ec = err * coef;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int el = 64 * r + lane;
+                const float ri = regI32 * qi[r], rj = regI32 * qj[r];
+                const float ni = (float)((double)qi[r] + a.lr * (ec * di[r] - (double)ri));     // :61
+                const float nj = (float)((double)qj[r] - a.lr * (ec * dj[r] + (double)rj));     // :62
+                const float dq = ni - nj;
+                x[r] = x[r] + err * (double)dq;                                                  // :63
+                if (el < k) { stg_f32(wq + i * k + el, ni); stg_f32(wq + j * k + el, nj); }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) stg_f64(xr + (e - e0) * k + el, x[r]); }
+    }
+    const double pc = 1.0 / (double)a.rho * coef;                       // :68, left to right
+    for (int64_t e = e0; e < e1; ++e) {
+        const int64_t s = ra.loc_i[e];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int el = 64 * r + lane;
+            if (el < k) {
+                const double p = ldg_f64(wp + s * k + el);
+                stg_f64(wp + s * k + el, p + a.lr * (pc * ldg_f64(xr + (e - e0) * k + el) - a.regI * p));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // what this user changed: working row - round-start row, added to the round's difference buffers
+    for (int64_t s = 0; s < q1 - q0; ++s) {
+        const int64_t it = ra.uq_items[q0 + s];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int el = 64 * r + lane;
+            if (el < k) {
+                const float dq = ldg_f32(wq + s * k + el) - a.Q[it * k + el];
+                if (dq != 0.0f) atomicAdd(ra.dQ + it * k + el, dq);
+                const double dp = ldg_f64(wp + s * k + el) - a.P[it * k + el];
+                if (dp != 0.0) atomicAdd(ra.dP + it * k + el, dp);
+            }
+        }
+        if (lane == 0) { const double db = ldg_f64(wb + s) - a.Bi[it]; if (db != 0.0) atomicAdd(ra.dB + it, db); }
+    }
+    if (lane == 0) atomicAdd(a.out, half_sq);
+}
+
+// end of a round: model += summed differences, buffers cleared
+__global__ void __launch_bounds__(256) k_fism_apply(double *P, float *Q, double *Bi, double *dP, float *dQ, double *dB, int64_t n, int k) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tot = n * k;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += stride) {
+        const float q = dQ[t];
+        if (q != 0.0f) { Q[t] = Q[t] + q; dQ[t] = 0.0f; }
+        const double p = dP[t];
+        if (p != 0.0) { P[t] = P[t] + p; dP[t] = 0.0; }
+    }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const double b = dB[t];
+        if (b != 0.0) { Bi[t] = Bi[t] + b; dB[t] = 0.0; }
+    }
 }
 
 // FISM.py:70: sum(P*P), sum(Q*Q) (float32 products), Bi.Bi -- accumulated in double.

@@ -37,6 +37,7 @@ struct ScanArgs {
     float *out_scores;
     int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events, [2] exact re-scores (bf16 path)
     const float *tile_norm_max; // max ||Q[i]||_2 over each tile of 32 items (bf16 pre-filter margin); unused by the f32 kernel
+    const float *tile_norm_sufmax; // max of tile_norm_max over this and all later tiles (early exit of the bf16 kernel)
     int true_topn;             // 0: the reference's overwrite-scan (default); 1: a real top-N (ties: lower id first)
 };
 
@@ -118,6 +119,21 @@ __global__ void __launch_bounds__(256) k_tile_norm_max(const float *Q, int64_t n
     s += __shfl_xor(s, 32);
     for (int off = 16; off >= 1; off >>= 1) s = fmaxf(s, __shfl_xor(s, off));
     if (lane == 0) out[tl] = __builtin_sqrtf(s) * 1.0001f;      // the two half sums round differently: keep it an upper bound
+}
+
+// sufmax[t] = max(norm_max[t], norm_max[t+1], ...): one wave, chunks of 64 tiles from the back
+__global__ void __launch_bounds__(64) k_tile_norm_sufmax(const float *norm_max, int64_t ntile, float *sufmax) {
+    const int lane = threadIdx.x;
+    float carry = 0.0f;
+    for (int64_t hi = ntile; hi > 0; hi -= 64) {
+        const int64_t t = hi - 64 + lane;
+        float v = t >= 0 ? norm_max[t] : 0.0f;
+        // inclusive max-scan towards lower lanes: lane l gets max over lanes l..63
+        for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_down(v, off); if (lane + off < 64) v = fmaxf(v, o); }
+        v = fmaxf(v, carry);
+        if (t >= 0) sufmax[t] = v;
+        carry = __shfl(v, 0);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_scores_one(const float *pu, const float *Q, int64_t n, int k, float *out) {
@@ -323,6 +339,11 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         ss += __shfl_xor(ss, 32);
         mu = __builtin_sqrtf(ss) * (1.01f / 128.0f);           // 2^-7 ||P_u||, 1 % slack for the norm roundings
     }
+    // Cauchy-Schwarz: no exact score of a tile exceeds ||P_u|| * max ||Q_i|| (both rounded up: the chain's own rounding,
+    // k * 2^-24 relative, is far inside the 1e-4 slacks).  A full list whose threshold is at or above that bound cannot
+    // change in the tile: the wave skips the tile when that holds for all its users, the workgroup stops when it holds
+    // for all its users against the largest norm of ALL remaining tiles.
+    const float pn = mu * (128.0f * 1.0001f / 1.01f);
 
     // item tiles: global -> registers (one tile ahead) -> LDS, float4 granularity
     constexpr int PF4 = (kScanTile * K / 4 + 255) / 256;
@@ -373,6 +394,9 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         const int64_t it0 = t * kScanTile;
         const float *tb = tile + cur * kScanTile * LD;
         if (t + 1 < ntiles) fetch(it0 + kScanTile);
+        // can any user of this wave still change in this tile?  (mask cursors of skipped tiles catch up in the next scanned one)
+        const bool settled = !(h == 0 && uvalid) || (S.cnt == N && pn * nu <= S.thr);
+        if (__ballot(!settled) != 0ull) {
 
         // bf16 scores with ITEMS as rows and USERS as columns: lane (r,h) supplies A[item r][16*s+8*h+j]
         // from item r's fp32 row in the tile and B[16*s+8*h+j][user r] from its user's fragments, and
@@ -404,7 +428,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         if (h == 0 && uvalid) {
             uint32_t mb = 0u;
             while (mnext < it0 + kScanTile) {
-                mb |= 1u << (uint32_t)(mnext - it0);
+                if (mnext >= it0) mb |= 1u << (uint32_t)(mnext - it0);      // masked items of skipped tiles just pass by
                 ++mcur;
                 mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
             }
@@ -444,9 +468,16 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
             s_prev = sc;
         }
         thr_lane = __shfl(S.thr, r);                           // lane (r,1) filters with its user's threshold too
+        }
         if (t + 1 < ntiles) commit(cur ^ 1);
         nu = nu_next;
-        __syncthreads();
+        if ((t & 15) == 15 && t + 1 < ntiles) {
+            // every 16 tiles: does any user of the workgroup still have a chance in ANY remaining tile?
+            const bool done = !(h == 0 && uvalid) || (S.cnt == N && pn * a.tile_norm_sufmax[t + 1] <= S.thr);
+            if (!__syncthreads_or(!done)) break;
+        } else {
+            __syncthreads();
+        }
     }
 
     if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }

@@ -99,6 +99,11 @@ struct yue_ctx {
     DevBuf<float> fQ;
     DevBuf<int64_t> f_ptr;
     DevBuf<int32_t> f_items, f_negs, f_ids, f_flags;
+    // FISM rounds: touched-item lists, positions, working copies, difference buffers
+    DevBuf<int64_t> f_uq_ptr, f_neg_ptr;
+    DevBuf<int32_t> f_uq_items, f_loc_i, f_loc_j;
+    DevBuf<float> f_wq, f_dQ;
+    DevBuf<double> f_wp, f_wb, f_dP, f_dB;
     int64_t fn = 0;
     int fk = 0;
     // RCCL
@@ -389,6 +394,8 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release();
     c->fP.release(); c->fBi.release(); c->f_coef.release(); c->f_x.release(); c->f_hist.release(); c->f_scores.release();
     c->f_out_sc.release(); c->fQ.release(); c->f_ptr.release(); c->f_items.release(); c->f_negs.release(); c->f_ids.release(); c->f_flags.release();
+    c->f_uq_ptr.release(); c->f_neg_ptr.release(); c->f_uq_items.release(); c->f_loc_i.release(); c->f_loc_j.release();
+    c->f_wq.release(); c->f_dQ.release(); c->f_wp.release(); c->f_wb.release(); c->f_dP.release(); c->f_dB.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return YUE_OK;
@@ -766,9 +773,11 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     }
     HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
     const int64_t ntile = (c->n + 31) / 32;
-    HIPCHK(c->s_norms.resize(ntile));
+    HIPCHK(c->s_norms.resize(2 * ntile));
     hipLaunchKernelGGL(yue::k_tile_norm_max, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
+    hipLaunchKernelGGL(yue::k_tile_norm_sufmax, dim3(1), dim3(64), 0, c->stream, c->s_norms.p, ntile, c->s_norms.p + ntile);
     sa.tile_norm_max = c->s_norms.p;
+    sa.tile_norm_sufmax = c->s_norms.p + ntile;
     const hipEvent_t t0 = c->ev_scan0, t1 = c->ev_scan1;
     HIPCHK(hipEventRecord(t0, c->stream));
     int rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32);
@@ -855,6 +864,82 @@ int yue_fism_epoch(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_t
         case 1: hipLaunchKernelGGL(yue::k_fism_epoch<1>, dim3(1), dim3(64), 0, c->stream, a); break;
         case 2: hipLaunchKernelGGL(yue::k_fism_epoch<2>, dim3(1), dim3(64), 0, c->stream, a); break;
         default: hipLaunchKernelGGL(yue::k_fism_epoch<4>, dim3(1), dim3(64), 0, c->stream, a); break;
+    }
+    hipLaunchKernelGGL(yue::k_fism_sumsq, dim3(256), dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, sc + 1);
+    HIPCHK(hipGetLastError());
+    double h[4];
+    HIPCHK(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (half_sq_out) *half_sq_out = h[0];
+    if (sumsq3_out) { sumsq3_out[0] = h[1]; sumsq3_out[1] = h[2]; sumsq3_out[2] = h[3]; }
+    return YUE_OK;
+}
+
+int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_t *ev_i, const int32_t *negs, int64_t n_negs, int rho,
+                    const double *coef, int64_t round_users, double lr, double regI, double regB, double *half_sq_out, double *sumsq3_out) {
+    if (!c || c->fn == 0) return fail(YUE_ERR_ARG, "yue_fism_rounds: no FISM model uploaded");
+    if (m <= 0 || rho < 1 || round_users < 1 || !coef || (n_negs > 0 && !negs)) return fail(YUE_ERR_ARG, "yue_fism_rounds: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = fism_upload_rows(c, user_ptr, m, ev_i, "yue_fism_rounds");
+    if (rc) return rc;
+    const int64_t E = user_ptr[m];
+    // per user: first draw, the sorted unique list of the items it touches, and every event's / draw's position in it
+    std::vector<int64_t> neg_ptr((size_t)m + 1, 0), uq_ptr((size_t)m + 1, 0);
+    for (int64_t u = 0; u < m; ++u) { const int64_t nu = user_ptr[u + 1] - user_ptr[u]; neg_ptr[(size_t)u + 1] = neg_ptr[(size_t)u] + (nu > 1 ? nu * rho : 0); }
+    if (neg_ptr[(size_t)m] != n_negs) return fail(YUE_ERR_ARG, "yue_fism_rounds: need rho negatives per event of every user with more than one event (" + std::to_string(neg_ptr[(size_t)m]) + "), got " + std::to_string(n_negs));
+    for (int64_t t = 0; t < n_negs; ++t) if (negs[t] < 0 || negs[t] >= c->fn) return fail(YUE_ERR_ARG, "yue_fism_rounds: negative item id out of range");
+    std::vector<int32_t> uq_items, loc_i((size_t)std::max<int64_t>(E, 1)), loc_j((size_t)std::max<int64_t>(n_negs, 1)), tmp;
+    for (int64_t u = 0; u < m; ++u) {
+        tmp.assign(ev_i + user_ptr[u], ev_i + user_ptr[u + 1]);
+        tmp.insert(tmp.end(), negs + neg_ptr[(size_t)u], negs + neg_ptr[(size_t)u + 1]);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (int64_t e = user_ptr[u]; e < user_ptr[u + 1]; ++e) loc_i[(size_t)e] = (int32_t)(std::lower_bound(tmp.begin(), tmp.end(), ev_i[e]) - tmp.begin());
+        for (int64_t t = neg_ptr[(size_t)u]; t < neg_ptr[(size_t)u + 1]; ++t) loc_j[(size_t)t] = (int32_t)(std::lower_bound(tmp.begin(), tmp.end(), negs[t]) - tmp.begin());
+        uq_items.insert(uq_items.end(), tmp.begin(), tmp.end());
+        uq_ptr[(size_t)u + 1] = (int64_t)uq_items.size();
+    }
+    int64_t rows_max = 1, ev_max = 1;                          // working rows / events of the largest round
+    for (int64_t u0 = 0; u0 < m; u0 += round_users) {
+        const int64_t u1 = std::min(m, u0 + round_users);
+        rows_max = std::max(rows_max, uq_ptr[(size_t)u1] - uq_ptr[(size_t)u0]);
+        ev_max = std::max(ev_max, user_ptr[u1] - user_ptr[u0]);
+    }
+    const size_t nk = (size_t)c->fn * c->fk;
+    HIPCHK(c->f_uq_ptr.resize((size_t)m + 1)); HIPCHK(c->f_neg_ptr.resize((size_t)m + 1)); HIPCHK(c->f_uq_items.resize(std::max<size_t>(uq_items.size(), 1)));
+    HIPCHK(c->f_loc_i.resize(loc_i.size())); HIPCHK(c->f_loc_j.resize(loc_j.size())); HIPCHK(c->f_coef.resize((size_t)m));
+    HIPCHK(c->f_wq.resize((size_t)rows_max * c->fk)); HIPCHK(c->f_wp.resize((size_t)rows_max * c->fk)); HIPCHK(c->f_wb.resize((size_t)rows_max));
+    HIPCHK(c->f_x.resize((size_t)ev_max * c->fk));
+    HIPCHK(c->f_dQ.resize(nk)); HIPCHK(c->f_dP.resize(nk)); HIPCHK(c->f_dB.resize((size_t)c->fn));
+    HIPCHK(hipMemcpyAsync(c->f_uq_ptr.p, uq_ptr.data(), ((size_t)m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->f_neg_ptr.p, neg_ptr.data(), ((size_t)m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    if (!uq_items.empty()) HIPCHK(hipMemcpyAsync(c->f_uq_items.p, uq_items.data(), uq_items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (E > 0) HIPCHK(hipMemcpyAsync(c->f_loc_i.p, loc_i.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (n_negs > 0) HIPCHK(hipMemcpyAsync(c->f_loc_j.p, loc_j.data(), (size_t)n_negs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->f_coef.p, coef, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->f_dQ.p, 0, nk * sizeof(float), c->stream));
+    HIPCHK(hipMemsetAsync(c->f_dP.p, 0, nk * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->f_dB.p, 0, (size_t)c->fn * sizeof(double), c->stream));
+    double *sc = c->scal.p + yue::kNllSlots;              // [0] half_sq, [1..3] sums of squares
+    HIPCHK(hipMemsetAsync(sc, 0, 4 * sizeof(double), c->stream));
+    yue::FismArgs a{};
+    a.P = c->fP.p; a.Q = c->fQ.p; a.Bi = c->fBi.p; a.n = c->fn; a.k = c->fk;
+    a.user_ptr = c->f_ptr.p; a.m = m; a.ev_i = c->f_items.p; a.negs = nullptr; a.rho = rho; a.coef = c->f_coef.p;
+    a.lr = lr; a.regI = regI; a.regB = regB; a.x_rows = c->f_x.p; a.out = sc;
+    yue::FismRoundArgs ra{};
+    ra.uq_ptr = c->f_uq_ptr.p; ra.uq_items = c->f_uq_items.p; ra.loc_i = c->f_loc_i.p; ra.loc_j = c->f_loc_j.p; ra.neg_ptr = c->f_neg_ptr.p;
+    ra.wq = c->f_wq.p; ra.wp = c->f_wp.p; ra.wb = c->f_wb.p; ra.dQ = c->f_dQ.p; ra.dP = c->f_dP.p; ra.dB = c->f_dB.p;
+    const dim3 apply_grid((unsigned)std::min<int64_t>(1024, (int64_t)(nk + 255) / 256));
+    for (int64_t u0 = 0; u0 < m; u0 += round_users) {
+        const int64_t u1 = std::min(m, u0 + round_users);
+        ra.u_begin = u0; ra.u_end = u1; ra.w_base = uq_ptr[(size_t)u0];
+        const dim3 grid((unsigned)((u1 - u0 + 3) / 4));
+        switch (kr_of(c->fk)) {
+            case 1: hipLaunchKernelGGL(yue::k_fism_round<1>, grid, dim3(256), 0, c->stream, a, ra); break;
+            case 2: hipLaunchKernelGGL(yue::k_fism_round<2>, grid, dim3(256), 0, c->stream, a, ra); break;
+            default: hipLaunchKernelGGL(yue::k_fism_round<4>, grid, dim3(256), 0, c->stream, a, ra); break;
+        }
+        hipLaunchKernelGGL(yue::k_fism_apply, apply_grid, dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->f_dP.p, c->f_dQ.p, c->f_dB.p, c->fn, c->fk);
     }
     hipLaunchKernelGGL(yue::k_fism_sumsq, dim3(256), dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, sc + 1);
     HIPCHK(hipGetLastError());

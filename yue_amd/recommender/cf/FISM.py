@@ -7,7 +7,9 @@ float64 [items, k] (item-history factors), ``Q`` float32 [items, k], ``Bi`` floa
 (FISM.py:15-18).  Negatives are drawn on the host exactly as the reference draws them (``choice`` over
 the item names + rejection, FISM.py:50-53), so a seeded ``random`` gives the reference's stream; the
 device then runs the epoch in the reference's strictly sequential order.  Config: the reference's
-``FISM=-rho R -alpha A`` line; ``bpr.hip=-gpu N`` selects the device as for BPR.
+``FISM=-rho R -alpha A`` line; ``bpr.hip=-gpu N`` selects the device as for BPR.  One optional addition:
+``FISM=-rho R -alpha A -round U`` trains in rounds of U users (throughput form, yue_fism_rounds:
+every user of a round starts from the round-start model; U = 1, the default, is the reference's pass).
 """
 from random import choice
 
@@ -27,6 +29,7 @@ class FISM(IterativeRecommender):
         options = LineConfig(self.config['FISM'])
         self.rho = max(1, int(options['-rho']))
         self.alpha = float(options['-alpha'])
+        self.roundUsers = max(1, int(options['-round'])) if options.contains('-round') else 1
 
     def initModel(self):
         super(FISM, self).initModel()                    # draws the base class's P, Q first (kept: same random stream)
@@ -77,7 +80,10 @@ class FISM(IterativeRecommender):
         iteration = 0
         while iteration < self.maxIter:
             negs = self._draw_negatives(itemList, listened)
-            half_sq, sumP, sumQ, sumB = dev.fism_epoch(user_ptr, ev_i, negs, self.rho, coef, self.lRate, self.regI, self.regB)
+            if self.roundUsers > 1:      # throughput form: rounds of users
+                half_sq, sumP, sumQ, sumB = dev.fism_rounds(user_ptr, ev_i, negs, self.rho, coef, self.roundUsers, self.lRate, self.regI, self.regB)
+            else:                        # the reference's strictly sequential pass
+                half_sq, sumP, sumQ, sumB = dev.fism_epoch(user_ptr, ev_i, negs, self.rho, coef, self.lRate, self.regI, self.regB)
             # FISM.py:70 with NumPy's scalar types: (P*P).sum() and Bi.dot(Bi) are float64, (Q*Q).sum() is a float32
             # (so `regI * ...` is a float32); the total stays float64
             self.loss = np.float64(half_sq) + (self.regU * np.float64(sumP) + self.regI * np.float32(sumQ) + self.regB * np.float64(sumB))
