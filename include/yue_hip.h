@@ -16,6 +16,7 @@
  *                                       (recommender/cf/BPR.py:32-35,42-45; data/record.py:138-163)
  *   yue_bpr_replay                      the epoch body recommender/cf/BPR.py:42-58 on an explicit
  *                                       (u,i,j) stream, exact sequential semantics
+ *   yue_cune_steps                      the two-level BPR loop of recommender/advanced/CUNE.py:126-172
  *   yue_bpr_rounds / yue_bpr_epoch      the same triplet update in rounds (DESIGN.md "S-round"),
  *                                       yue_bpr_epoch fuses the negative sampler of BPR.py:46-48
  *   yue_sumsq                           the regulariser sums of BPR.py:59
@@ -70,6 +71,14 @@ int yue_set_interactions(yue_ctx *ctx, const int64_t *indptr, const int32_t *ind
  * device).  j[t] < 0 skips the triplet.  nll_out = sum of -log(s). */
 int yue_bpr_replay(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
                    double lr, double regU, double regI, double *nll_out);
+
+/* CUNE's two-level BPR steps (reference recommender/advanced/CUNE.py:126-172) on explicit (u, i, k, j) steps, exact
+ * sequential semantics in the given order: k[t] >= 0 is the step with a friends' item k ((i over k), then (k over j) with
+ * margin and step scaled by 1/s, then the decays :156-159), k[t] < 0 the plain (i over j) step of :166-172.
+ * loss_out[T] = every step's -log sigmoid term(s) on its final rows (the caller adds them up the way :161 / :175 do).
+ * The user network / Word2Vec stage that produces the friends' items (CUNE.py:34-118) is not part of this library. */
+int yue_cune_steps(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *k, const int32_t *j, int64_t T,
+                   double s, double lr, double regU, double regI, double *loss_out);
 
 /* Explicit triplets, S-round semantics: rounds are round_ptr[r]..round_ptr[r+1] (n_rounds+1 entries). */
 int yue_bpr_rounds(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j,

@@ -283,16 +283,126 @@ def g8_fism(tmp, logs, datasets):
     case('fism_d3_k130_e3', 'd3', 130, 3, 3, '0.5', '10,20')
 
 
+def g9_cune(tmp, logs, datasets):
+    """CUNE's two-level BPR training loop: recommender/advanced/CUNE.py:120-178.  The class imports
+    gensim's Word2Vec for its user-network stage (absent here): empty module objects named gensim / gensim.models /
+    gensim.models.word2vec satisfy the import; the embedding stage (:34-106) is NOT run.  The training loop's text is
+    taken from the reference file at run time (from its "Training..." line to the end of buildModel), dedented and
+    exec'd against a real CUNE instance whose PositiveSet is built as :107-113 builds it and whose IPositiveSet (the
+    friends' items, the product of the skipped stage) is a seeded synthetic one: most users get 1..15 items they have
+    not listened to (duplicates allowed), the others none -- both branches of the loop run.  ``choice`` is wrapped to
+    log every draw.  Fixtures: initial / final P, Q, the (u, i, k, j) stream in processing order (k = -1: the plain
+    branch), loss (value and type), learning rate, printed lines."""
+    for name in ('gensim', 'gensim.models', 'gensim.models.word2vec'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import recommender.advanced.CUNE as cune_mod
+    src = open(os.path.join(REF, 'recommender/advanced/CUNE.py')).read().splitlines()
+    a = next(t for t, ln in enumerate(src) if "print ('Training...')" in ln)
+    b = next(t for t, ln in enumerate(src) if ln.strip().startswith('def predict'))
+    body = textwrap.dedent('\n'.join(src[a:b]))
+    code = 'def train(self):\n' + textwrap.indent(body, '    ')
+    seed = 20260007
+
+    def conf_for(log_path, k, iters, sval):
+        out = []
+        for ln in open(os.path.join(REF, 'config/CUNE.conf')).read().splitlines():
+            key = ln.split('=')[0]
+            if key == 'record':
+                ln = 'record=' + log_path
+            elif key == 'num.factors':
+                ln = 'num.factors=%d' % k
+            elif key == 'num.max.iter':
+                ln = 'num.max.iter=%d' % iters
+            elif key == 'CUNE':
+                ln = 'CUNE=-T 20 -L 10 -l 20 -w 5 -k 50 -s %s -ep 10' % sval
+            elif key == 'output.setup':
+                ln = 'output.setup=on -dir ' + os.path.join(tmp, 'results_cune') + '/'
+            out.append(ln)
+        path = os.path.join(tmp, 'cune_%d_%d.conf' % (k, iters))
+        open(path, 'w').write('\n'.join(out) + '\n')
+        return path
+
+    def case(tag, log_name, k, iters, sval):
+        conf = Config(conf_for(logs[log_name], k, iters, sval))
+        rec, _ = quiet(cune_mod.CUNE, conf, load_train(conf), [])
+        rec.readConfiguration()
+        random.seed(seed)
+        np.random.seed(seed)
+        rec.initModel()
+        P0, Q0 = rec.P.copy(), rec.Q.copy()
+        d, rt = rec.data, rec.recType
+        rec.PositiveSet = defaultdict(list)                  # CUNE.py:107-113
+        rec.IPositiveSet = defaultdict(list)
+        for user in d.userRecord:
+            for event in d.userRecord[user]:
+                rec.PositiveSet[user].append(event[rt])
+        names = list(d.name2id[rt].keys())
+        rs = np.random.RandomState(seed + 1)
+        for user in rec.PositiveSet:
+            if rs.rand() < 0.8:
+                mine = set(rec.PositiveSet[user])
+                pool = [x for x in names if x not in mine]
+                rec.IPositiveSet[user] = [pool[t] for t in rs.randint(0, len(pool), size=int(rs.randint(1, 16)))]
+        draws = []
+
+        def logged_choice(seq):
+            x = random.choice(seq)
+            draws.append(x)
+            return x
+        scope = dict(cune_mod.__dict__)
+        scope['choice'] = logged_choice
+        exec(code, scope)
+        random.seed(seed + 2)
+        _, out = quiet(scope['train'], rec)
+        # the (u, i, k, j) stream in processing order, from the draw log and the loop's structure (:123-172)
+        it = iter(draws)
+        uu, ii, kk, jj = [], [], [], []
+        n_epochs = len([ln for ln in out.splitlines() if 'iteration' in ln])
+        for _ep in range(n_epochs):
+            for user in rec.PositiveSet:
+                for item in rec.PositiveSet[user]:
+                    for _n in range(3):
+                        kname = next(it) if len(rec.IPositiveSet[user]) > 0 else None
+                        jname = next(it)
+                        while user in d.listened[rt][jname]:
+                            jname = next(it)
+                        uu.append(d.getId(user, 'user')); ii.append(d.getId(item, rt))
+                        kk.append(d.getId(kname, rt) if kname is not None else -1); jj.append(d.getId(jname, rt))
+        assert next(it, None) is None
+        ip_ptr = np.zeros(d.getSize('user') + 1, np.int64)
+        ip_rows = {}
+        for user in rec.PositiveSet:
+            ip_rows[d.getId(user, 'user')] = [d.getId(x, rt) for x in rec.IPositiveSet[user]]
+        flat = []
+        for u in range(d.getSize('user')):
+            flat += ip_rows.get(u, [])
+            ip_ptr[u + 1] = len(flat)
+        ev_u, ev_i = record_arrays(rec)
+        lines = [ln for ln in out.splitlines() if 'iteration' in ln]
+        np.savez_compressed(os.path.join(OUT, 'g9_%s.npz' % tag), seed=seed, k=k, iters=n_epochs, s=np.float64(rec.s), m=d.getSize('user'), n=Q0.shape[0],
+                            ev_u=ev_u, ev_i=ev_i, ip_ptr=ip_ptr, ip_items=np.array(flat, np.int32),
+                            u=np.array(uu, np.int32), i=np.array(ii, np.int32), kk=np.array(kk, np.int32), j=np.array(jj, np.int32),
+                            P0=P0, Q0=Q0, P=rec.P, Q=rec.Q, loss=np.float64(rec.loss), lRate=np.float64(rec.lRate))
+        json.dump({'lines': lines, 'dataset': datasets[log_name], 'loss_type': type(rec.loss).__name__, 'dtypes': [str(rec.P.dtype), str(rec.Q.dtype)],
+                   'lr0': 0.02, 'lr_max': 0.1, 'regU': rec.regU, 'regI': rec.regI}, open(os.path.join(OUT, 'g9_%s.json' % tag), 'w'), indent=1)
+
+    case('cune_d2_k20_e2', 'd2', 20, 2, '2')
+    case('cune_d3_k64_e1', 'd3', 64, 1, '3')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix='yue_gold_')
-    if '--only-fism' in sys.argv:
+    if '--only-fism' in sys.argv or '--only-cune' in sys.argv:
         datasets = {'c1': (1000, 1000, 20), 'd2': (200, 300, 20), 'd3': (120, 200, 20)}
         logs = {}
         for name, (m, n, d) in datasets.items():
             logs[name] = os.path.join(tmp, name + '.txt')
             synth.write_text_log(logs[name], m, n, d)
-        g8_fism(tmp, logs, datasets)
+        if '--only-fism' in sys.argv:
+            g8_fism(tmp, logs, datasets)
+        else:
+            g9_cune(tmp, logs, datasets)
         return
     g1_config()
     g7_measure()
@@ -387,6 +497,7 @@ def main():
     json.dump({'measure': m6, 'stdout': out6}, open(os.path.join(OUT, 'g6_ranking_performance.json'), 'w'), indent=1)
 
     g8_fism(tmp, logs, datasets)
+    g9_cune(tmp, logs, datasets)
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('golden files:', sorted(os.listdir(OUT)), 'total bytes', tot)

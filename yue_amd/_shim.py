@@ -20,7 +20,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/yue_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy', 'yue_sync',
            'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
-           'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
+           'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_cune_steps', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
            'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
            'yue_default_round_events', 'yue_epoch_plan',
@@ -169,6 +169,17 @@ class Device(object):
         nll = C.c_double()
         self._chk(self._lib.yue_bpr_rounds(self._ctx, a, b, c, d, C.c_int64(len(rp) - 1), C.c_double(lr), C.c_double(regU), C.c_double(regI), C.byref(nll)))
         return nll.value
+
+    def cune_steps(self, u, i, k, j, s, lr, regU, regI):
+        """CUNE's two-level BPR steps in order (k < 0: plain step).  Returns the per-step losses (float64[T])."""
+        u, a = _i32(u)
+        i, b = _i32(i)
+        k, c = _i32(k)
+        j, d = _i32(j)
+        loss = np.empty(len(u), np.float64)
+        self._chk(self._lib.yue_cune_steps(self._ctx, a, b, c, d, C.c_int64(len(u)), C.c_double(s), C.c_double(lr), C.c_double(regU), C.c_double(regI),
+                                           loss.ctypes.data_as(C.POINTER(C.c_double))))
+        return loss
 
     def default_round_events(self):
         out = C.c_int64()

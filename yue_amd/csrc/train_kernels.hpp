@@ -183,6 +183,112 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 }
 
 // ------------------------------------------------------------------------------------------
+// CUNE's two-level BPR step (reference recommender/advanced/CUNE.py:126-172), exact sequential
+// semantics: ONE wave walks the given (u, i, k, j) steps in order (every step of a user rewrites P[u]: the chain is
+// sequential anyway).  k >= 0: (i over k) then (k over j, margin and step scaled by 1/s), then the four decays;
+// k < 0: the plain (i over j) step without decay.  As the reference writes it, the sigmoid is evaluated again, on the
+// rows already updated, in every one of the statements.  Rounding as NumPy does it: float32 rows, coefficients
+// formed in double and rounded to float32 once, the 1/s factor of the margin applied in float32, products and sums
+// rounded separately.  loss_out[t] = the step's two (one) -log sigmoid terms on the final rows.
+// ------------------------------------------------------------------------------------------
+struct CuneArgs {
+    float *P, *Q;
+    int k;
+    const int32_t *u, *i, *kk, *j;
+    int64_t T;
+    double inv_s, lr;            // 1 / s as Python forms it
+    float inv_s32;               // the same, as the float32 NumPy multiplies the float32 margin with
+    float ru, ri;                // float32(lr * regU), float32(lr * regI)
+    double *loss_out;
+};
+
+template <int KR>
+__global__ void __launch_bounds__(64) k_cune_steps(CuneArgs a) {
+    const int lane = threadIdx.x;
+    const int k = a.k;
+    auto dot = [&](const float (&x)[KR], const float (&y)[KR]) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) { const float m = x[r] * y[r]; acc = acc + m; }
+        return wave_sum(acc);
+    };
+    auto sig = [](double x) { return 1.0 / (1.0 + exp(-x)); };
+    for (int64_t t = 0; t < a.T; ++t) {
+        const int64_t u = a.u[t], i = a.i[t], kq = a.kk[t], j = a.j[t];
+        float p[KR], qi[KR], qk[KR], qj[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = 64 * r + lane;
+            p[r] = e < k ? __hip_atomic_load(a.P + u * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            qi[r] = e < k ? __hip_atomic_load(a.Q + i * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            qj[r] = e < k ? __hip_atomic_load(a.Q + j * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            qk[r] = (e < k && kq >= 0) ? __hip_atomic_load(a.Q + kq * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        }
+        // k == j is possible (both are merely items the user has not listened to): the two names then mean ONE row,
+        // every write through one of them is seen through the other (NumPy updates the same memory)
+        const bool same = kq == j;
+        double loss;
+        if (kq >= 0) {
+            float c = (float)(a.lr * (1.0 - sig((double)(dot(p, qi) - dot(p, qk)))));                       // :133
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float d = qi[r] - qk[r]; const float td = c * d; p[r] = p[r] + td; }
+            c = (float)(a.lr * (1.0 - sig((double)(dot(p, qi) - dot(p, qk)))));                             // :135
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float tq = c * p[r]; qi[r] = qi[r] + tq; }
+            c = (float)(a.lr * (1.0 - sig((double)(dot(p, qi) - dot(p, qk)))));                             // :137
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float tq = c * p[r]; qk[r] = qk[r] - tq; if (same) qj[r] = qk[r]; }
+            float m2 = a.inv_s32 * (dot(p, qk) - dot(p, qj));
+            c = (float)(a.inv_s * a.lr * (1.0 - sig((double)m2)));                                          // :148
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float d = qk[r] - qj[r]; const float td = c * d; p[r] = p[r] + td; }
+            m2 = a.inv_s32 * (dot(p, qk) - dot(p, qj));
+            c = (float)(a.inv_s * a.lr * (1.0 - sig((double)m2)));                                          // :151
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float tq = c * p[r]; qk[r] = qk[r] + tq; if (same) qj[r] = qk[r]; }
+            m2 = a.inv_s32 * (dot(p, qk) - dot(p, qj));
+            c = (float)(a.inv_s * a.lr * (1.0 - sig((double)m2)));                                          // :153
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float tq = c * p[r]; qj[r] = qj[r] - tq; if (same) qk[r] = qj[r]; }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {                                                                  // :156-159
+                const float rp = a.ru * p[r]; p[r] = p[r] - rp;
+                const float r1 = a.ri * qi[r]; qi[r] = qi[r] - r1;
+                const float r2 = a.ri * qj[r]; qj[r] = qj[r] - r2;
+                if (same) qk[r] = qj[r];
+                const float r3 = a.ri * qk[r]; qk[r] = qk[r] - r3;
+                if (same) qj[r] = qk[r];
+            }
+            const float m3 = a.inv_s32 * (dot(p, qk) - dot(p, qj));
+            loss = -log(sig((double)(dot(p, qi) - dot(p, qk)))) - log(sig((double)m3));                     // :161-162
+        } else {
+            float c = (float)(a.lr * (1.0 - sig((double)(dot(p, qi) - dot(p, qj)))));                       // :168
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float d = qi[r] - qj[r]; const float td = c * d; p[r] = p[r] + td; }
+            c = (float)(a.lr * (1.0 - sig((double)(dot(p, qi) - dot(p, qj)))));                             // :169
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float tq = c * p[r]; qi[r] = qi[r] + tq; }
+            c = (float)(a.lr * (1.0 - sig((double)(dot(p, qi) - dot(p, qj)))));                             // :170
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float tq = c * p[r]; qj[r] = qj[r] - tq; }
+            loss = -log(sig((double)(dot(p, qi) - dot(p, qj))));                                            // :172
+        }
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = 64 * r + lane;
+            if (e < k) {
+                __hip_atomic_store(a.P + u * k + e, p[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.Q + i * k + e, qi[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.Q + j * k + e, qj[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kq >= 0 && !same) __hip_atomic_store(a.Q + kq * k + e, qk[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (lane == 0) a.loss_out[t] = loss;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // S-round launch.  Every wave first takes the tickets of TPW events of the NEXT round (touch count +
 // staging-slot table of their two item rows, user-row flush counts; lanes TPW .. 2 TPW - 1), then
 // updates TPW events of THIS round -- no separate workgroups for the counting, so every resident

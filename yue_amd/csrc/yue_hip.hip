@@ -74,7 +74,8 @@ struct yue_ctx {
 #endif
     DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
     DevBuf<int64_t> indptr;
-    DevBuf<int32_t> xu, xi, xj;          // explicit triplets (replay / rounds)
+    DevBuf<int32_t> xu, xi, xj, xk;      // explicit triplets (replay / rounds), CUNE's fourth row
+    DevBuf<double> x_loss;               // per-step losses (CUNE)
     DevBuf<double> scal;                 // [kNllSlots] nll slots + [8] scalars
     std::vector<int64_t> h_ev_ptr;       // host copy: user -> first event
     // scoring scratch
@@ -389,7 +390,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->tab0.release(); c->tab1.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
-    c->xu.release(); c->xi.release(); c->xj.release(); c->scal.release();
+    c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
     c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release();
     c->fP.release(); c->fBi.release(); c->f_coef.release(); c->f_x.release(); c->f_hist.release(); c->f_scores.release();
@@ -554,6 +555,36 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     if ((rc = run_rounds(c, a, bounds, 1, [](int64_t) { return YUE_OK; }))) { reset_round_state(c); return rc; }
     HIPCHK(hipGetLastError());
     return read_scalars(c, nll_out, nullptr, nullptr);
+}
+
+int yue_cune_steps(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *k, const int32_t *j, int64_t T,
+                   double s, double lr, double regU, double regI, double *loss_out) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_cune_steps: no factors uploaded");
+    if (T < 0 || (T > 0 && (!u || !i || !k || !j || !loss_out)) || !(s > 0.0)) return fail(YUE_ERR_ARG, "yue_cune_steps: bad argument");
+    if (T == 0) return YUE_OK;
+    HIPCHK(hipSetDevice(c->device));
+    for (int64_t t = 0; t < T; ++t) {
+        if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] < 0 || j[t] >= c->n || k[t] >= c->n) return fail(YUE_ERR_ARG, "yue_cune_steps: step " + std::to_string(t) + " out of range");
+        if (i[t] == j[t] || k[t] == i[t]) return fail(YUE_ERR_ARG, "yue_cune_steps: step " + std::to_string(t) + ": i must differ from k and from j (k == j is allowed, as in the reference)");
+    }
+    int rc = upload_triplets(c, u, i, j, T);
+    if (rc) return rc;
+    HIPCHK(c->xk.resize(T)); HIPCHK(c->x_loss.resize(T));
+    HIPCHK(hipMemcpyAsync(c->xk.p, k, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    yue::CuneArgs a{};
+    a.P = c->P.p; a.Q = c->Q.p; a.k = c->k; a.u = c->xu.p; a.i = c->xi.p; a.kk = c->xk.p; a.j = c->xj.p; a.T = T;
+    a.inv_s = 1.0 / s; a.inv_s32 = (float)(1.0 / s); a.lr = lr;
+    a.ru = (float)(lr * regU); a.ri = (float)(lr * regI);          // CUNE.py:156: python-float product, cast to float32 by NumPy
+    a.loss_out = c->x_loss.p;
+    switch (kr_of(c->k)) {
+        case 1: hipLaunchKernelGGL(yue::k_cune_steps<1>, dim3(1), dim3(64), 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL(yue::k_cune_steps<2>, dim3(1), dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(yue::k_cune_steps<4>, dim3(1), dim3(64), 0, c->stream, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(loss_out, c->x_loss.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
 }
 
 int yue_sample_negatives(yue_ctx *c, uint64_t seed, uint32_t epoch, int32_t *j_out) {

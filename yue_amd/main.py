@@ -4,7 +4,7 @@ import time
 from .tool.config import Config
 from .yue import Yue
 
-MENU = {'1': 'BPR', '2': 'FISM'}
+MENU = {'1': 'BPR', '2': 'FISM', 'a1': 'CUNE'}
 
 
 def main():
@@ -13,6 +13,8 @@ def main():
     print('=' * 80)
     print('CF-based Recommenders:')
     print('1. BPR   2. FISM')
+    print('Advanced Recommenders:')
+    print('a1. CUNE (training loop; needs -friends, see recommender/advanced/CUNE.py)')
     print('=' * 80)
     order = input('Please enter the num of the algorithm to run it:')
     start = time.time()
