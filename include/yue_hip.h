@@ -72,6 +72,16 @@ int yue_set_interactions(yue_ctx *ctx, const int64_t *indptr, const int32_t *ind
 int yue_bpr_replay(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
                    double lr, double regU, double regI, double *nll_out);
 
+/* The reference's LIVE path (recommender/cf/BPR.py:83-129, a TensorFlow-1 graph): one minibatch step on the fed triplets
+ * (the reference feeds 512 events x 100 negatives, :65-81) -- loss = sum softplus(-(U[u].V[i] - U[u].V[j])) + reg * (l2_loss of
+ * the three gathered row sets), then Adam (beta1 0.9, beta2 0.999, epsilon 1e-8, TF-1 sparse apply = dense Adam with zero
+ * gradients on untouched rows) on both factor matrices, all in float32.  step = 1, 2, ... (Adam's bias correction).
+ * yue_adam_reset clears the moments (also done implicitly when the factor shapes change).  PARITY UNPINNED: no TensorFlow
+ * here; the checker is oracle/numpy_adam.py, a restatement of the graph as written. */
+int yue_adam_reset(yue_ctx *ctx);
+int yue_adam_step(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
+                  double lr, double reg, int64_t step, double *loss_out);
+
 /* CUNE's two-level BPR steps (reference recommender/advanced/CUNE.py:126-172) on explicit (u, i, k, j) steps, exact
  * sequential semantics in the given order: k[t] >= 0 is the step with a friends' item k ((i over k), then (k over j) with
  * margin and step scaled by 1/s, then the decays :156-159), k[t] < 0 the plain (i over j) step of :166-172.
@@ -139,6 +149,10 @@ int yue_get_kernel_timing(yue_ctx *ctx, double *total_ms, int64_t *launches_time
 /* Last yue_topn_scan: time of its scoring kernel (HIP events), state-machine events, exact re-scores
  * done behind the bf16 pre-filter, and whether the bf16 pre-filter kernel ran (k in 16/32/64/128). */
 int yue_get_scan_stats(yue_ctx *ctx, double *kernel_ms, int64_t *events, int64_t *rescored, int *used_bf16);
+/* Last yue_topn_scan: 32-user x 32-item tiles the kernel actually scored, and the tiles of the full user x item product.  The
+ * bf16 kernel skips a tile -- and stops a workgroup -- when a norm bound shows that none of its exact scores can reach any of the
+ * users' thresholds (||P_u|| * max ||Q_i|| <= threshold; exact: the lists do not change). */
+int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total);
 
 /* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score

@@ -20,8 +20,8 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/yue_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy', 'yue_sync',
            'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
-           'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_cune_steps', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
-           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_set_option',
+           'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_cune_steps', 'yue_adam_reset', 'yue_adam_step', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
+           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_get_scan_work', 'yue_set_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
            'yue_default_round_events', 'yue_epoch_plan',
            'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_rounds', 'yue_fism_scores', 'yue_fism_topn_scan']
@@ -181,6 +181,18 @@ class Device(object):
                                            loss.ctypes.data_as(C.POINTER(C.c_double))))
         return loss
 
+    def adam_reset(self):
+        self._chk(self._lib.yue_adam_reset(self._ctx))
+
+    def adam_step(self, u, i, j, lr, reg, step):
+        """One minibatch step of the reference's live TF-style path (softplus loss + l2 terms, Adam).  Returns total_loss."""
+        u, a = _i32(u)
+        i, b = _i32(i)
+        j, c = _i32(j)
+        loss = C.c_double()
+        self._chk(self._lib.yue_adam_step(self._ctx, a, b, c, C.c_int64(len(u)), C.c_double(lr), C.c_double(reg), C.c_int64(step), C.byref(loss)))
+        return loss.value
+
     def default_round_events(self):
         out = C.c_int64()
         self._chk(self._lib.yue_default_round_events(self._ctx, C.byref(out)))
@@ -232,6 +244,12 @@ class Device(object):
         ms, ev, rs, bf = C.c_double(), C.c_int64(), C.c_int64(), C.c_int()
         self._chk(self._lib.yue_get_scan_stats(self._ctx, C.byref(ms), C.byref(ev), C.byref(rs), C.byref(bf)))
         return ms.value, ev.value, rs.value, bool(bf.value)
+
+    def scan_work(self):
+        """(tiles scored, tiles of the full product) of the last topn_scan (32 users x 32 items each)."""
+        done, total = C.c_int64(), C.c_int64()
+        self._chk(self._lib.yue_get_scan_work(self._ctx, C.byref(done), C.byref(total)))
+        return done.value, total.value
 
     def set_option(self, name, value):
         self._chk(self._lib.yue_set_option(self._ctx, name.encode(), C.c_int64(value)))

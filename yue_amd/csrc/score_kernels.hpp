@@ -36,6 +36,7 @@ struct ScanArgs {
     int32_t *out_ids;
     float *out_scores;
     int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events, [2] exact re-scores (bf16 path)
+    unsigned long long *work; // [0] 32-user x 32-item tiles actually scored (the bf16 kernel skips tiles that cannot matter)
     const float *tile_norm_max; // max ||Q[i]||_2 over each tile of 32 items (bf16 pre-filter margin); unused by the f32 kernel
     const float *tile_norm_sufmax; // max of tile_norm_max over this and all later tiles (early exit of the bf16 kernel)
     int true_topn;             // 0: the reference's overwrite-scan (default); 1: a real top-N (ties: lower id first)
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
     }
 
     if (h == 0 && uvalid) scan_finish(S, N, a.flags);
+    if (lane == 0) atomicAdd(a.work, (unsigned long long)ntiles);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -374,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
     S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;
     S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
     int rescored = 0;
+    unsigned tiles_done = 0;                                   // tiles this wave scored (wave-uniform)
     float thr_lane = -INFINITY;
     int64_t mcur = 0, mend = 0;
     int32_t mnext = 0x7fffffff;
@@ -397,6 +400,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         // can any user of this wave still change in this tile?  (mask cursors of skipped tiles catch up in the next scanned one)
         const bool settled = !(h == 0 && uvalid) || (S.cnt == N && pn * nu <= S.thr);
         if (__ballot(!settled) != 0ull) {
+        ++tiles_done;
 
         // bf16 scores with ITEMS as rows and USERS as columns: lane (r,h) supplies A[item r][16*s+8*h+j]
         // from item r's fp32 row in the tile and B[16*s+8*h+j][user r] from its user's fragments, and
@@ -481,6 +485,7 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
     }
 
     if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
+    if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
 }
 
 template <int K2>

@@ -183,6 +183,102 @@ __global__ void __launch_bounds__(256) k_bpr_level(TrainArgs a, int64_t e_begin,
 }
 
 // ------------------------------------------------------------------------------------------
+// The reference's live path (recommender/cf/BPR.py:83-129): one minibatch step of the TensorFlow-1
+// graph -- softplus(-(u.vi - u.vj)) summed over the fed triplets plus reg * l2_loss of the three gathered row sets, Adam on
+// both embedding matrices -- as two kernels.  Parity unpinned (no TensorFlow here): the checker is oracle/numpy_adam.py.
+//   k_mb_grad: a wave takes 32 consecutive triplets (the reference feeds 100 negatives per positive event, so consecutive
+//     triplets share u and i: their rows are loaded once per run, their gradient rows are summed in registers and added
+//     once per run with float atomics; every negative's gradient row is added as it comes), all in float32 as TensorFlow
+//     computes; loss partials in double slots.
+//   k_adam: dense Adam over a matrix (TF-1's sparse apply decays m and v and moves EVERY row: a zero gradient on the
+//     untouched ones), gradient buffer cleared for the next step.
+// ------------------------------------------------------------------------------------------
+struct MbArgs {
+    const float *U, *V;
+    float *gU, *gV;
+    int k;
+    const int32_t *u, *i, *j;
+    int64_t T;
+    float reg;
+    double *loss_slots;
+};
+
+template <int KR>
+__global__ void __launch_bounds__(256) k_mb_grad(MbArgs a) {
+    constexpr int CH = 32;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t t0 = wave * CH;
+    if (t0 >= a.T) return;
+    const int64_t t1 = t0 + CH < a.T ? t0 + CH : a.T;
+    const int k = a.k;
+    float pu[KR], vi[KR], gu[KR], gvi[KR];
+    int64_t cu = -1, ci = -1;
+    float dui = 0.0f, su = 0.0f, si = 0.0f;          // u.vi and the two squared norms of the current run
+    double loss = 0.0;
+    auto flush = [&]() {
+        if (cu < 0) return;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = 64 * r + lane;
+            if (e < k) { atomicAdd(a.gU + cu * k + e, gu[r]); atomicAdd(a.gV + ci * k + e, gvi[r]); }
+        }
+    };
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t u = a.u[t], i = a.i[t], j = a.j[t];
+        if (u != cu || i != ci) {
+            flush();
+            cu = u; ci = i;
+            float d = 0.0f, q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int e = 64 * r + lane;
+                pu[r] = e < k ? a.U[u * k + e] : 0.0f;
+                vi[r] = e < k ? a.V[i * k + e] : 0.0f;
+                gu[r] = 0.0f; gvi[r] = 0.0f;
+                d = __builtin_fmaf(pu[r], vi[r], d); q1 = __builtin_fmaf(pu[r], pu[r], q1); q2 = __builtin_fmaf(vi[r], vi[r], q2);
+            }
+            dui = wave_sum(d); su = wave_sum(q1); si = wave_sum(q2);
+        }
+        float vn[KR];
+        float d = 0.0f, q3 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = 64 * r + lane;
+            vn[r] = e < k ? a.V[j * k + e] : 0.0f;
+            d = __builtin_fmaf(pu[r], vn[r], d); q3 = __builtin_fmaf(vn[r], vn[r], q3);
+        }
+        const float err = dui - wave_sum(d);                                 // BPR.py:101
+        const float sn = wave_sum(q3);
+        const float ax = __builtin_fabsf(err);
+        loss += (double)(fmaxf(-err, 0.0f) + log1pf(expf(-ax)));             // softplus(-err), :102
+        loss += (double)(0.5f * a.reg * (su + si + sn));                     // the three l2 terms of this triplet, :104-107
+        const float g = -1.0f / (1.0f + expf(err));                          // d softplus(-e) / d e = -sigmoid(-e)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = 64 * r + lane;
+            gu[r] = gu[r] + (g * (vi[r] - vn[r]) + a.reg * pu[r]);
+            gvi[r] = gvi[r] + (g * pu[r] + a.reg * vi[r]);
+            if (e < k) atomicAdd(a.gV + j * k + e, -g * pu[r] + a.reg * vn[r]);
+        }
+    }
+    flush();
+    if (lane == 0) atomicAdd(a.loss_slots + (wave & (kNllSlots - 1)), loss);
+}
+
+__global__ void __launch_bounds__(256) k_adam(float *var, float *m, float *v, float *grad, int64_t count, float lr_t, float beta1, float beta2, float eps) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+        const float g = grad[t];
+        const float m1 = beta1 * m[t] + (1.0f - beta1) * g;
+        const float v1 = beta2 * v[t] + ((1.0f - beta2) * g) * g;
+        m[t] = m1; v[t] = v1;
+        var[t] = var[t] - lr_t * m1 / (__builtin_sqrtf(v1) + eps);
+        if (g != 0.0f) grad[t] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // CUNE's two-level BPR step (reference recommender/advanced/CUNE.py:126-172), exact sequential
 // semantics: ONE wave walks the given (u, i, k, j) steps in order (every step of a user rewrites P[u]: the chain is
 // sequential anyway).  k >= 0: (i over k) then (k over j, margin and step scaled by 1/s), then the four decays;

@@ -76,6 +76,8 @@ struct yue_ctx {
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> xu, xi, xj, xk;      // explicit triplets (replay / rounds), CUNE's fourth row
     DevBuf<double> x_loss;               // per-step losses (CUNE)
+    DevBuf<float> aU_m, aU_v, aV_m, aV_v;  // Adam moments of the live TF-style path (yue_adam_step); gradients use dP / dQ
+    int64_t adam_m = 0, adam_n = 0; int adam_k = 0;
     DevBuf<double> scal;                 // [kNllSlots] nll slots + [8] scalars
     std::vector<int64_t> h_ev_ptr;       // host copy: user -> first event
     // scoring scratch
@@ -83,7 +85,8 @@ struct yue_ctx {
     DevBuf<int64_t> s_mask_ptr;
     DevBuf<float> s_scores, s_row, s_norms;
     double scan_ms = 0.0;
-    int64_t scan_events = 0, scan_rescored = 0;
+    int64_t scan_events = 0, scan_rescored = 0, scan_tiles_done = 0, scan_tiles_total = 0;
+    DevBuf<unsigned long long> s_work;
     int scan_used_bf16 = 0;
     // options (yue_set_option)
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
@@ -391,8 +394,9 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->tab0.release(); c->tab1.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
+    c->aU_m.release(); c->aU_v.release(); c->aV_m.release(); c->aV_v.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
-    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release();
+    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release(); c->s_work.release();
     c->fP.release(); c->fBi.release(); c->f_coef.release(); c->f_x.release(); c->f_hist.release(); c->f_scores.release();
     c->f_out_sc.release(); c->fQ.release(); c->f_ptr.release(); c->f_items.release(); c->f_negs.release(); c->f_ids.release(); c->f_flags.release();
     c->f_uq_ptr.release(); c->f_neg_ptr.release(); c->f_uq_items.release(); c->f_loc_i.release(); c->f_loc_j.release();
@@ -587,6 +591,47 @@ int yue_cune_steps(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     return YUE_OK;
 }
 
+int yue_adam_reset(yue_ctx *c) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_adam_reset: no factors uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t mk = (size_t)c->m * c->k, nk = (size_t)c->n * c->k;
+    HIPCHK(c->aU_m.resize(mk)); HIPCHK(c->aU_v.resize(mk)); HIPCHK(c->aV_m.resize(nk)); HIPCHK(c->aV_v.resize(nk));
+    HIPCHK(hipMemsetAsync(c->aU_m.p, 0, mk * sizeof(float), c->stream)); HIPCHK(hipMemsetAsync(c->aU_v.p, 0, mk * sizeof(float), c->stream));
+    HIPCHK(hipMemsetAsync(c->aV_m.p, 0, nk * sizeof(float), c->stream)); HIPCHK(hipMemsetAsync(c->aV_v.p, 0, nk * sizeof(float), c->stream));
+    HIPCHK(hipMemsetAsync(c->dP.p, 0, mk * sizeof(float), c->stream)); HIPCHK(hipMemsetAsync(c->dQ.p, 0, nk * sizeof(float), c->stream));
+    c->adam_m = c->m; c->adam_n = c->n; c->adam_k = c->k;
+    return YUE_OK;
+}
+
+int yue_adam_step(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T, double lr, double reg, int64_t step, double *loss_out) {
+    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_adam_step: no factors uploaded");
+    if (T <= 0 || !u || !i || !j || step < 1) return fail(YUE_ERR_ARG, "yue_adam_step: bad argument (T > 0, step >= 1)");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->adam_m != c->m || c->adam_n != c->n || c->adam_k != c->k) { const int rc0 = yue_adam_reset(c); if (rc0) return rc0; }
+    for (int64_t t = 0; t < T; ++t)
+        if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] < 0 || j[t] >= c->n) return fail(YUE_ERR_ARG, "yue_adam_step: triplet " + std::to_string(t) + " out of range");
+    int rc = upload_triplets(c, u, i, j, T);
+    if (rc) return rc;
+    if ((rc = zero_scalars(c))) return rc;
+    yue::MbArgs a{};
+    a.U = c->P.p; a.V = c->Q.p; a.gU = c->dP.p; a.gV = c->dQ.p; a.k = c->k; a.u = c->xu.p; a.i = c->xi.p; a.j = c->xj.p; a.T = T;
+    a.reg = (float)reg; a.loss_slots = c->scal.p;
+    const dim3 grid((unsigned)(((T + 31) / 32 + 3) / 4));
+    switch (kr_of(c->k)) {
+        case 1: hipLaunchKernelGGL(yue::k_mb_grad<1>, grid, dim3(256), 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL(yue::k_mb_grad<2>, grid, dim3(256), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(yue::k_mb_grad<4>, grid, dim3(256), 0, c->stream, a); break;
+    }
+    // tf.train.AdamOptimizer defaults; lr_t as _prepare / _apply_sparse_shared form it
+    const double b1 = 0.9, b2 = 0.999;
+    const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)step)) / (1.0 - std::pow(b1, (double)step)));
+    const int64_t mk = c->m * (int64_t)c->k, nk = c->n * (int64_t)c->k;
+    hipLaunchKernelGGL(yue::k_adam, dim3((unsigned)std::min<int64_t>(8192, (mk + 255) / 256)), dim3(256), 0, c->stream, c->P.p, c->aU_m.p, c->aU_v.p, c->dP.p, mk, lr_t, 0.9f, 0.999f, 1e-8f);
+    hipLaunchKernelGGL(yue::k_adam, dim3((unsigned)std::min<int64_t>(8192, (nk + 255) / 256)), dim3(256), 0, c->stream, c->Q.p, c->aV_m.p, c->aV_v.p, c->dQ.p, nk, lr_t, 0.9f, 0.999f, 1e-8f);
+    HIPCHK(hipGetLastError());
+    return read_scalars(c, loss_out, nullptr, nullptr);
+}
+
 int yue_sample_negatives(yue_ctx *c, uint64_t seed, uint32_t epoch, int32_t *j_out) {
     if (!c || !c->have_inter || !j_out) return fail(YUE_ERR_ARG, "yue_sample_negatives: no interactions uploaded");
     HIPCHK(hipSetDevice(c->device));
@@ -727,6 +772,13 @@ int yue_get_scan_stats(yue_ctx *c, double *kernel_ms, int64_t *events, int64_t *
     return YUE_OK;
 }
 
+int yue_get_scan_work(yue_ctx *c, int64_t *tiles_scored, int64_t *tiles_total) {
+    if (!c) return fail(YUE_ERR_ARG, "null context");
+    if (tiles_scored) *tiles_scored = c->scan_tiles_done;
+    if (tiles_total) *tiles_total = c->scan_tiles_total;
+    return YUE_OK;
+}
+
 int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail(YUE_ERR_ARG, "yue_set_option: null argument");
     const std::string key(name);
@@ -781,7 +833,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     if (nu == 0) return YUE_OK;
     HIPCHK(hipSetDevice(c->device));
     for (int64_t t = 0; t < nu; ++t) if (users[t] < 0 || users[t] >= c->m) return fail(YUE_ERR_ARG, "yue_topn_scan: user id out of range");
-    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4));
+    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4)); HIPCHK(c->s_work.resize(1));
     HIPCHK(hipMemcpyAsync(c->s_users.p, users, nu * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     yue::ScanArgs sa{};
     sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
@@ -803,6 +855,8 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
         sa.mask_ptr = c->indptr.p; sa.mask_idx = c->indices.p; sa.mask_by_user = 1;
     }
     HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->s_work.p, 0, sizeof(unsigned long long), c->stream));
+    sa.work = c->s_work.p;
     const int64_t ntile = (c->n + 31) / 32;
     HIPCHK(c->s_norms.resize(2 * ntile));
     hipLaunchKernelGGL(yue::k_tile_norm_max, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
@@ -820,12 +874,16 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipMemcpyAsync(out_ids, c->s_ids.p, nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out_scores, c->s_scores.p, nu * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(flags, c->s_flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long work = 0;
+    HIPCHK(hipMemcpyAsync(&work, c->s_work.p, sizeof work, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, t0, t1));
     c->scan_ms = ms;
     c->scan_events = flags[1];
     c->scan_rescored = flags[2];
+    c->scan_tiles_done = (int64_t)work;
+    c->scan_tiles_total = ((nu + 31) / 32) * ntile;
     if (flags[0]) return fail(YUE_ERR_FEW_ITEMS, "a user has fewer than N candidate items (the reference raises IndexError, base/IterativeRecommender.py:126)");
     return YUE_OK;
 }

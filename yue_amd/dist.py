@@ -221,9 +221,29 @@ def epoch_block_plan(m, k, round_events, events_total, world):
     return {'user_block': ub, 'blocks_per_group': group, 'n_blocks': n_blocks, 'groups': groups}
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner on STDOUT when a communicator is created; a program whose stdout is a protocol
+    (bench.py: one JSON line) wraps the communicator set-up in this: file descriptor 1 points at stderr meanwhile."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._keep = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._keep, 1)
+        os.close(self._keep)
+        return False
+
+
 def attach_device(dev, cp):
     """Join `dev` (a yue_amd._shim.Device) to the job's RCCL communicator."""
     if cp.world > 1:
         from ._shim import comm_unique_id
-        ident = cp.broadcast_bytes(comm_unique_id() if cp.rank == 0 else None)
-        dev.comm_init(ident, cp.rank, cp.world)
+        with stdout_to_stderr():
+            ident = cp.broadcast_bytes(comm_unique_id() if cp.rank == 0 else None)
+            dev.comm_init(ident, cp.rank, cp.world)

@@ -13,6 +13,13 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
                                         throughput mode: counter-based sampler on the device,
                                         S-round semantics; -round N fixes the round size
                                         (auto = the device's default, 49,152 events on MI355X at k=128).
+  bpr.hip=-mode adam                    the reference's LIVE path (BPR.py:65-129, a TensorFlow-1 graph): every "iteration" is one
+                                        minibatch of 512 random training events x 100 rejection-sampled negatives (next_batch,
+                                        :65-81, same NumPy / random calls), loss = sum softplus(-x) + regU * l2 terms, Adam(lRate)
+                                        on both factor matrices (yue_adam_step), factors drawn as truncated_normal(0.005), the
+                                        300-user ranking_performance after every step.  PARITY UNPINNED: TensorFlow cannot be
+                                        installed here; the device path is checked against oracle/numpy_adam.py, a restatement
+                                        of the graph as written (tests/test_gpu_adam.py).
   -gpu N                                HIP device ordinal.
   -topn true                            evalRanking returns a real top-N (descending, ties: lower item id)
                                         instead of the reference's order-dependent overwrite-scan.
@@ -26,6 +33,16 @@ from ...data.arrays import ArrayRecord
 from ...tool.config import LineConfig
 
 
+def _truncated_normal(shape, stddev):
+    """tf.truncated_normal: values beyond two standard deviations are drawn again (NumPy's global stream)."""
+    x = np.random.normal(0.0, stddev, size=shape)
+    bad = np.abs(x) > 2 * stddev
+    while bad.any():
+        x[bad] = np.random.normal(0.0, stddev, size=int(bad.sum()))
+        bad = np.abs(x) > 2 * stddev
+    return x.astype(np.float32)
+
+
 class BPR(IterativeRecommender):
 
     def __init__(self, conf, trainingSet=None, testSet=None, fold='[1]'):
@@ -36,6 +53,9 @@ class BPR(IterativeRecommender):
         self.m = self.data.getSize('user')
         self.n = self.data.getSize(self.recType)
         self.train_size = len(self.data.trainingData)
+        if self._options()['-mode'] == 'adam':               # BPR.py:97-98: tf.truncated_normal(stddev=0.005), U first
+            self.P = _truncated_normal((self.m, self.k), 0.005)
+            self.Q = _truncated_normal((self.n, self.k), 0.005)
 
     def _options(self):
         opts = {'-mode': 'replay', '-round': 'auto', '-seed': '1'}
@@ -59,8 +79,50 @@ class BPR(IterativeRecommender):
                 out.append(item_ids[item_j])
         return np.asarray(out, np.int32)
 
+    def _next_batch(self, listened):
+        """BPR.py:65-81: 512 random training events, 100 rejection-sampled negatives each (random.randint over item ids)."""
+        from random import randint
+        train = self.data.trainingData
+        batch_idx = np.random.randint(len(train), size=512)
+        user_idx, item_idx, neg_idx = [], [], []
+        for idx in batch_idx:
+            uid = self.data.getId(train[idx]['user'], 'user')
+            tid = self.data.getId(train[idx][self.recType], self.recType)
+            mine = listened[uid]
+            for _ in range(100):
+                item_j = randint(0, self.n - 1)
+                while item_j in mine:
+                    item_j = randint(0, self.n - 1)
+                user_idx.append(uid)
+                item_idx.append(tid)
+                neg_idx.append(item_j)
+        return user_idx, item_idx, neg_idx
+
+    def _build_adam(self):
+        """The live path of the reference (BPR.py:83-129) with the graph evaluated by yue_adam_step."""
+        listened = {}
+        for user in self.data.userRecord:                        # :84-91
+            uid = self.data.getId(user, 'user')
+            listened[uid] = {self.data.getId(ev[self.recType], self.recType) for ev in self.data.userRecord[user]}
+        self._sync_factors_to_device()
+        dev = self.dev
+        dev.adam_reset()
+        for epoch in range(self.maxIter):
+            user_idx, item_idx, neg_idx = self._next_batch(listened)
+            loss = dev.adam_step(user_idx, item_idx, neg_idx, self.lRate, self.regU, epoch + 1)
+            print('iteration:', epoch, 'loss:', loss)
+            self.loss = loss
+            self.ranking_performance()                           # :129, the 300-user check after every step
+        dev.get_factors(self.P, self.Q)
+        self._device_factors_current = True
+
     def buildModel(self):
         opts = self._options()
+        if opts['-mode'] == 'adam':
+            if isinstance(self.data, ArrayRecord):
+                print('bpr.hip=-mode adam samples from the text log\'s training events; array-native data needs -mode epoch')
+                exit(-1)
+            return self._build_adam()
         if isinstance(self.data, ArrayRecord) and opts['-mode'] == 'replay':
             print('array-native data needs bpr.hip=-mode epoch (the replay mode samples over item names)')
             exit(-1)
