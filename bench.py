@@ -99,6 +99,16 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
             'hogwild': {'value': Sh / dth, 'cores': threads, 'sample': 'first %d triplets, the C loop raced by %d threads over slices of the stream (result depends on the interleaving), %.1f s' % (Sh, threads, dth)}}
 
 
+def round_kernel_label(dev, k):
+    kr = 1 if k <= 64 else 2 if k <= 128 else 4
+    path = dev.get_option('round_path')
+    if path == 2:
+        return 'k_round_m<KR=%d> + k_round_fold<KR=%d> (one round: update launch on the pre-pass metadata + rewrite of its contended rows)' % (kr, kr)
+    if path == 1:
+        return 'k_round_m<KR=%d> (update on the pre-pass metadata, contended rows finished by their last toucher)' % kr
+    return 'k_round<KR=%d> (update + touch tickets of the next round)' % kr
+
+
 def measured_traffic(workload, round_events):
     """(HBM bytes per launch of the dominant kernel, where the number comes from) from the newest committed
     rocprofv3 --pmc summary (profiles/r*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes);
@@ -298,7 +308,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
-    ap.add_argument('--round-events', type=int, default=0, help='events per S-round; 0 = the library\'s default for this device (one resident wave set)')
+    ap.add_argument('--round-events', type=int, default=0, help='events per S-round; 0 = the library\'s default for this device and problem (yue_default_round_events)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the scoring line (secondary.c5) of the default run')
     ap.add_argument('--scan-f32', action='store_true', help='scoring workloads: force the exact f32-MFMA kernel')
@@ -385,14 +395,14 @@ def main():
                                    % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),
                        'round_events': args.round_events, 'parallelism': 'items sharded x%d, users replicated' % world,
                        'setup_s': round(setup_s, 1), 'final_nll_per_triplet': nll / E},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_round<KR=%d> (update + touch tickets of the next round)' % (1 if k <= 64 else 2 if k <= 128 else 4),
+            'roofline': {'bound': 'hbm', 'kernel': round_kernel_label(dev, k),
                          'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                          'algorithmic_bytes_per_triplet': ab, 'launches_timed': k_launches,
                          'avg_launch_ms': (k_ms / k_launches) if k_launches else None,
                          'triplets_per_launch': (k_triplets / k_launches) if k_launches else None,
-                         'timing': 'HIP events on the library\'s stream around all round launches of each timed epoch (launch boundaries and the %d user-row '
-                                   'apply launches per epoch included): avg_launch_ms x launches per epoch <= ms_per_step by construction; the kernel-only average '
-                                   'is in the rocprofv3 summary under profiles/' % max(1, k_launches // max(1, args.steps) // 16),
+                         'timing': 'HIP events on the library\'s stream around all round launches of each timed epoch (a launch here = one round: its update '
+                                   'launch and its fold launch; launch boundaries and the user-row apply launches of the epoch included): avg_launch_ms x launches '
+                                   'per epoch <= ms_per_step by construction; the kernel-only averages are in the rocprofv3 summary under profiles/',
                          'traffic': traffic[0] if traffic else None, 'traffic_source': traffic[1] if traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -115,9 +115,12 @@ int yue_bpr_epoch(yue_ctx *ctx, uint64_t seed, uint32_t epoch, int64_t round_eve
 int yue_epoch_plan(int64_t m, int k, int64_t round_events, double events_total, int nranks,
                    int64_t *user_block, int64_t *blocks_per_group, int64_t *n_blocks);
 
-/* The default round size for the uploaded k on this device: the events one resident set of waves of the round
- * kernel takes (a launch is then a single wave generation); 49,152 on MI355X at k = 128.  Results depend on the
- * round size: pass an explicit value where runs must be comparable across devices. */
+/* The default round size of yue_bpr_epoch for the uploaded factors on this device.  One resident set of waves of the
+ * round kernel takes 57,344 events on MI355X at k = 128 (49,152 for the kernels that finish contended rows inside
+ * the launch: option round_fold / round_meta = 0, and yue_bpr_rounds); the default is up to 3 such sets, as long as
+ * a round holds at most one event per item row of this rank (job-wide average on a communicator: the call is then
+ * collective) -- 172,032 on BASELINE config 3.  Results depend on the round size: pass an
+ * explicit value where runs must be comparable across devices. */
 int yue_default_round_events(yue_ctx *ctx, int64_t *out);
 
 /* Negatives the device sampler draws for (seed, epoch): j_out[E], -1 where all attempts were rejected. */
@@ -158,12 +161,20 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
  *   "round_tpw" events per wave in the training round kernel: 0 = default (16 for k <= 64, 8 for k <= 128, else 4), 2, 4, 8, 16 (k <= 64 only)
  *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in
- *               staging rows (write-through stores, summed in event order by the last toucher);
+ *               staging rows (summed in event / ticket order when the row is rewritten);
  *               0: every contended row goes through float atomics
+ *   "round_meta" 1 (default): yue_bpr_epoch takes the touch metadata of all rounds from one pre-pass per epoch
+ *               (k_round_meta; item shards of up to 454,656 rows); 0: touches are counted inside the round launches (k_round)
+ *   "round_fold" 1 (default, with round_meta): a round's contended rows are rewritten by a fold launch behind its update
+ *               launch; 0: inside the update launch by their last toucher.  Also moves yue_default_round_events.
+ *   "fold_blocks" workgroups of the fold launch (default 1536)
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
  *               the reference's order-dependent overwrite-scan */
 int yue_set_option(yue_ctx *ctx, const char *name, int64_t value);
+/* Reads an option back; "round_path" = the kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_m with the
+ * retire phase inside, 2 k_round_m + k_round_fold. */
+int yue_get_option(yue_ctx *ctx, const char *name, int64_t *value);
 
 /*
  * FISM (reference recommender/cf/FISM.py) -- parity path: the reference's strictly

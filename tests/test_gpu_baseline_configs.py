@@ -2,7 +2,8 @@
 
   * config 3 (1M users x 200K items, k=128, 50M triplets, the device's default round size): one full
     epoch against the oracle's restatement of the same rounds (oracle/bpr_oracle.c: orc_bpr_rounds) --
-    the bench workload itself, at the real Zipf contention and the default W;
+    the bench workload itself, at the real Zipf contention and the default W (172,032: metadata pre-pass,
+    round launches without retire phase, fold launches);
   * one GPU's share of config 4 (10M users -> 5.1 GB of replicated user factors, a 125K-item shard,
     60M events) through the communicator code path (1-rank RCCL communicator: all-reduce + range apply
     on the second stream) against the same oracle (world = 1: the sharded spec IS the S-round oracle
@@ -55,7 +56,8 @@ def _epoch_vs_oracle(orc, dev, data, P0, Q0, seed, W, tag):
     assert eP < TOL and eQ < TOL
     assert xP < 1e-3 and xQ < 1e-3                            # element-wise, elements above 1e-3 (1 % of the value range)
     assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
-    assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
+    # double-precision sums of up to 1.3e9 fp32 squares, added in different orders on the two sides
+    assert abs(sp - orc.sumsq(P)) <= 1e-11 * sp and abs(sq - orc.sumsq(Q)) <= 1e-11 * sq
 
 
 def test_config3_full_epoch_matches_oracle(orc):

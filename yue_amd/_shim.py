@@ -21,7 +21,7 @@ UNIQUE_ID_BYTES = 128
 SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy', 'yue_sync',
            'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
            'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_cune_steps', 'yue_adam_reset', 'yue_adam_step', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
-           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_get_scan_work', 'yue_set_option',
+           'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_get_scan_work', 'yue_set_option', 'yue_get_option',
            'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
            'yue_default_round_events', 'yue_epoch_plan',
            'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_rounds', 'yue_fism_scores', 'yue_fism_topn_scan']
@@ -253,6 +253,11 @@ class Device(object):
 
     def set_option(self, name, value):
         self._chk(self._lib.yue_set_option(self._ctx, name.encode(), C.c_int64(value)))
+
+    def get_option(self, name):
+        out = C.c_int64()
+        self._chk(self._lib.yue_get_option(self._ctx, name.encode(), C.byref(out)))
+        return out.value
 
     # -- measurement ----------------------------------------------------------------------
     def set_kernel_timing(self, stride):

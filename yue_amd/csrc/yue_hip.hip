@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "train_kernels.hpp"
+#include "round_kernels.hpp"
 #include "score_kernels.hpp"
 #include "fism_kernels.hpp"
 
@@ -68,6 +69,12 @@ struct yue_ctx {
     // staged item rows (2 per event of the widest round) live behind the n item rows in the Q allocation,
     // so that "new row in place" and "new row to my staging row" are the same store with another offset
     bool staged = false;                         // the running call uses the staging rows
+    // epoch path: touch metadata of all rounds from one pre-pass (round_kernels.hpp)
+    DevBuf<uint32_t> meta_i, meta_j, row_cnt;
+    DevBuf<unsigned long long> round_rows;
+    DevBuf<uint2> fold;
+    DevBuf<int64_t> d_bounds;
+    std::vector<int64_t> h_bounds;               // outlives the asynchronous upload
 #ifdef YUE_STAMPS
     DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
     int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0;
@@ -93,6 +100,9 @@ struct yue_ctx {
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
+    int opt_round_fold = 1;              // epoch path with metadata: 1 contended rows rewritten by k_round_fold behind every round launch, 0 inside the launch (last toucher)
+    int opt_fold_blocks = 1536;           // workgroups of k_round_fold
+    int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
     // kernel timing
     int timing_stride = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -157,34 +167,58 @@ int tpw_of(const yue_ctx *c) {
     return kr == 4 ? 4 : kr == 2 ? 8 : 16;
 }
 
-// Default round size: as many events as ONE resident set of waves of the round kernel takes (workgroups of
-// 4 waves x TPW events), so that a launch is a single wave generation -- the measured optimum on MI355X
-// (49,152 at k = 128).
-int default_round_events(yue_ctx *c, int64_t *out) {
+// Epoch path: the pre-pass over all rounds (k_round_meta) -- one LDS word per item row of a range, ranges of at most
+// kMetaRangeMax rows.  Past kMetaRangesMax ranges every work item would re-read its round too often: the caller then
+// stays on k_round (touches counted inside the round launches).
+constexpr int64_t kMetaRangeMax = 37 * 1024;       // 148 KB of the CU's 160 KB of LDS
+constexpr int64_t kMetaRangesMax = 12;
+constexpr int64_t kRoundGenerationsMax = 3;
+
+bool meta_path_fits(const yue_ctx *c) { return c->opt_round_meta && c->n <= kMetaRangeMax * kMetaRangesMax; }
+bool fold_path(const yue_ctx *c) { return meta_path_fits(c) && c->opt_round_fold; }
+
+// Default round size.
+//   * k_round / k_round_m with the retire phase inside the launch: the events ONE resident set of waves takes (workgroups
+//     of 4 waves x TPW events) -- a launch is a single wave generation, the measured optimum of a kernel whose waves wait
+//     for each other (49,152 at k = 128);
+//   * the fold path (k_round_m without retire + k_round_fold: no wave waits for another): up to kRoundGenerationsMax
+//     resident sets, as long as a round stays at or below one event per item row (at most ~2 touches of a row per round:
+//     the staleness of the S-round semantics is bounded relative to the item count) -- 3 x 57,344 on C3.
+// `n_rows` = item rows per rank (job-wide average on a communicator, so that all ranks agree).
+int default_round_events(yue_ctx *c, double n_rows, int64_t *out) {
     const int tpw = tpw_of(c);
+    const bool fold = fold_path(c);
     int per_cu = 0, cus = 0;
     hipError_t e = hipSuccess;
+#define YUE_OCC(KR_, TPW_) \
+    e = fold ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_m<KR_, TPW_, false>, 256, 0) \
+             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<KR_, TPW_>, 256, 0); \
+    break;
     switch (kr_of(c->k) * 16 + tpw) {
-        case 1 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 8>, 256, 0); break;
-        case 1 * 16 + 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 16>, 256, 0); break;
-        case 2 * 16 + 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 8>, 256, 0); break;
-        case 4 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<4, 4>, 256, 0); break;
-        case 1 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 4>, 256, 0); break;
-        case 2 * 16 + 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 4>, 256, 0); break;
-        case 1 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<1, 2>, 256, 0); break;
-        case 2 * 16 + 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<2, 2>, 256, 0); break;
+        case 1 * 16 + 8: YUE_OCC(1, 8)
+        case 1 * 16 + 16: YUE_OCC(1, 16)
+        case 2 * 16 + 8: YUE_OCC(2, 8)
+        case 4 * 16 + 4: YUE_OCC(4, 4)
+        case 1 * 16 + 4: YUE_OCC(1, 4)
+        case 2 * 16 + 4: YUE_OCC(2, 4)
+        case 1 * 16 + 2: YUE_OCC(1, 2)
+        case 2 * 16 + 2: YUE_OCC(2, 2)
         default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
     }
+#undef YUE_OCC
     HIPCHK(e);
-    // The round kernels use all 106 SGPRs (yue_amd/csrc/resource_usage.txt); a CU admits at most
-    // floor(800 / (ceil(106 / 16) * 16 + 16)) = 6 workgroups of them whatever the occupancy query says
-    // (MI355X_MICROARCH.md, residency rule; seen on C2: the query answers 7, a round sized for 7 runs as two generations).
-    per_cu = std::min(per_cu, 6);
+    // A CU admits at most floor(800 / (ceil(SGPRs / 16) * 16 + 16)) workgroups of 4 waves whatever the occupancy query
+    // says (MI355X_MICROARCH.md, residency rule; seen on C2: the query answers 7, a round sized for 7 runs as two
+    // generations): k_round uses all 106 SGPRs -> 6; k_round_m is compiled with at most 96 -> 7
+    // (yue_amd/csrc/resource_usage.txt).
+    per_cu = std::min(per_cu, fold ? 7 : 6);
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     const double slots = (double)per_cu * (double)cus;                    // resident workgroups of 256 threads
     int64_t w = (int64_t)(slots * 4.0 * tpw);
     w -= w % 1024;
-    *out = std::max<int64_t>(w, 1024);
+    w = std::max<int64_t>(w, 1024);
+    if (fold) w *= std::min<int64_t>(kRoundGenerationsMax, std::max<int64_t>(1, (int64_t)(n_rows / (double)w)));
+    *out = w;
     return YUE_OK;
 }
 
@@ -231,10 +265,94 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     return YUE_OK;
 }
 
+int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int64_t> &bounds) {
+    const int64_t R = (int64_t)bounds.size() - 1;
+    const int64_t E = bounds.back();
+    HIPCHK(c->meta_i.resize((size_t)std::max<int64_t>(E, 1))); HIPCHK(c->meta_j.resize((size_t)std::max<int64_t>(E, 1)));
+    if (c->row_cnt.n < (size_t)c->n) {
+        HIPCHK(c->row_cnt.resize((size_t)c->n));
+        HIPCHK(hipMemsetAsync(c->row_cnt.p, 0, c->row_cnt.n * sizeof(uint32_t), c->stream));
+    }
+    HIPCHK(c->round_rows.resize((size_t)R)); HIPCHK(c->d_bounds.resize((size_t)R + 1));
+    if (c->h_bounds != bounds) {                       // the same blocks epoch after epoch: uploaded once
+        HIPCHK(hipStreamSynchronize(c->stream));       // an earlier upload may still read h_bounds
+        c->h_bounds = bounds;
+        HIPCHK(hipMemcpyAsync(c->d_bounds.p, c->h_bounds.data(), (size_t)(R + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipMemsetAsync(c->round_rows.p, 0, (size_t)R * sizeof(unsigned long long), c->stream));
+    HIPCHK(c->fold.resize((size_t)(E + 4 * R + 8)));
+    yue::MetaArgs ma{};
+    ma.ev_i = a.ev_i; ma.ev_j = a.ev_j; ma.bounds = c->d_bounds.p; ma.R = R; ma.n = (int32_t)c->n;
+    ma.G = (int32_t)((c->n + kMetaRangeMax - 1) / kMetaRangeMax);
+    ma.range = (int32_t)((c->n + ma.G - 1) / ma.G);
+    ma.chunk = (ma.range + 1023) / 1024; ma.chunk |= 1;
+    ma.stage_max = c->staged ? yue::kStageMax : 1u;
+    ma.meta_i = c->meta_i.p; ma.meta_j = c->meta_j.p; ma.round_rows = c->round_rows.p; ma.fold = c->fold.p;
+    const size_t lds = (size_t)ma.range * sizeof(uint32_t);
+    HIPCHK(hipFuncSetAttribute((const void *)yue::k_round_meta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0, cus = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_meta, 1024, lds));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int64_t grid = std::min<int64_t>(R * ma.G, (int64_t)std::max(per_cu, 1) * cus);
+    hipLaunchKernelGGL(yue::k_round_meta, dim3((unsigned)grid), dim3(1024), lds, c->stream, ma);
+    HIPCHK(hipGetLastError());
+    return YUE_OK;
+}
+
+int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t round_index) {
+    yue::RoundMArgs ra{};
+    ra.e_begin = e0; ra.e_end = e1; ra.row_cnt = c->row_cnt.p; ra.staged = c->staged ? 1 : 0;
+    const int tpw = tpw_of(c);
+    const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks == 0) return YUE_OK;
+    const dim3 grid((unsigned)blocks), block(256);
+#ifdef YUE_STAMPS
+    yue::TrainArgs a = a_in;
+    a.stamps = nullptr;
+    if (c->update_launches++ == c->stamp_launch) {
+        HIPCHK(c->stamps.resize((size_t)waves * 8));
+        HIPCHK(hipMemsetAsync(c->stamps.p, 0, (size_t)waves * 64, c->stream));
+        a.stamps = c->stamps.p;
+        c->stamp_waves = waves;
+    }
+#else
+    const yue::TrainArgs &a = a_in;
+#endif
+    const uint32_t *mi = c->meta_i.p, *mj = c->meta_j.p;
+#define YUE_RM(KR_, TPW_) \
+    if (c->opt_round_fold) hipLaunchKernelGGL((yue::k_round_m<KR_, TPW_, false>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); \
+    else hipLaunchKernelGGL((yue::k_round_m<KR_, TPW_, true>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); \
+    break;
+    switch (kr_of(c->k) * 16 + tpw) {
+        case 1 * 16 + 8: YUE_RM(1, 8)
+        case 1 * 16 + 16: YUE_RM(1, 16)
+        case 2 * 16 + 8: YUE_RM(2, 8)
+        case 4 * 16 + 4: YUE_RM(4, 4)
+        case 1 * 16 + 4: YUE_RM(1, 4)
+        case 2 * 16 + 4: YUE_RM(2, 4)
+        case 1 * 16 + 2: YUE_RM(1, 2)
+        case 2 * 16 + 2: YUE_RM(2, 2)
+        default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
+    }
+#undef YUE_RM
+    if (c->opt_round_fold) {
+        yue::FoldArgs f{};
+        f.fold = c->fold.p + yue::fold_base(e0, round_index); f.round_rows = c->round_rows.p + round_index; f.Q = a.Q; f.dQ = a.dQ; f.stage = a.stage; f.k = c->k; f.capacity = (uint32_t)((e1 - e0) & ~(int64_t)3);
+        const dim3 fgrid((unsigned)std::min<int64_t>(c->opt_fold_blocks, std::max<int64_t>(1, (e1 - e0 + 15) / 16)));
+        switch (kr_of(c->k)) {
+            case 1: hipLaunchKernelGGL(yue::k_round_fold<1>, fgrid, block, 0, c->stream, f); break;
+            case 2: hipLaunchKernelGGL(yue::k_round_fold<2>, fgrid, block, 0, c->stream, f); break;
+            default: hipLaunchKernelGGL(yue::k_round_fold<4>, fgrid, block, 0, c->stream, f); break;
+        }
+    }
+    return YUE_OK;
+}
+
 // Runs the non-empty rounds bounds[r]..bounds[r+1] in order.  after_round(r) is called once the
 // launches of round r are queued (the communicator path hooks its all-reduce there).
 template <typename F>
-int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int apply_p, F after_round) {
+int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int apply_p, F after_round, bool meta = false) {
     const int64_t R = (int64_t)bounds.size() - 1;
     // staging rows: two per event of the largest round, addressed with 31-bit byte offsets
     int64_t widest = 0;
@@ -251,14 +369,18 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
             c->Q = bigger;
             a.Q = c->Q.p;
         }
-        HIPCHK(c->tab0.resize((size_t)c->n * yue::kStageMax));
-        HIPCHK(c->tab1.resize((size_t)c->n * yue::kStageMax));
+        if (!meta) {
+            HIPCHK(c->tab0.resize((size_t)c->n * yue::kStageMax));
+            HIPCHK(c->tab1.resize((size_t)c->n * yue::kStageMax));
+        }
         a.stage = c->Q.p + (size_t)c->n * c->k;
     }
     std::vector<int64_t> ne;                                // indices of non-empty rounds
     for (int64_t r = 0; r < R; ++r) if (bounds[(size_t)r + 1] > bounds[(size_t)r]) ne.push_back(r);
     int rc;
-    if (!ne.empty()) {      // prologue: negatives + touch counts of the first round
+    if (meta) {
+        if (!ne.empty() && (rc = launch_round_meta(c, a, bounds))) return rc;
+    } else if (!ne.empty()) {      // prologue: touch counts of the first round
         const int64_t r0 = ne[0];
         if ((rc = launch_round(c, a, 0, 0, bounds[(size_t)r0], bounds[(size_t)r0 + 1], 1, apply_p))) return rc;
     }
@@ -281,7 +403,7 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
             const int64_t e0 = bounds[(size_t)r], e1 = bounds[(size_t)r + 1];
             int64_t n0 = 0, n1 = 0;
             if (pos + 1 < ne.size()) { n0 = bounds[(size_t)ne[pos + 1]]; n1 = bounds[(size_t)ne[pos + 1] + 1]; }
-            if ((rc = launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), apply_p))) return rc;
+            if ((rc = meta ? launch_round_m(c, a, e0, e1, r) : launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), apply_p))) return rc;
             ++pos;
         }
         if ((rc = after_round(r))) return rc;
@@ -303,6 +425,7 @@ void reset_round_state(yue_ctx *c) {
     if (c->cnt1.p) (void)hipMemsetAsync(c->cnt1.p, 0, c->cnt1.n * sizeof(unsigned long long), c->stream);
     if (c->cntp0.p) (void)hipMemsetAsync(c->cntp0.p, 0, c->cntp0.n * sizeof(uint32_t), c->stream);
     if (c->cntp1.p) (void)hipMemsetAsync(c->cntp1.p, 0, c->cntp1.n * sizeof(uint32_t), c->stream);
+    if (c->row_cnt.p) (void)hipMemsetAsync(c->row_cnt.p, 0, c->row_cnt.n * sizeof(uint32_t), c->stream);
     if (c->dP.p) (void)hipMemsetAsync(c->dP.p, 0, c->dP.n * sizeof(float), c->stream);
     if (c->dQ.p) (void)hipMemsetAsync(c->dQ.p, 0, c->dQ.n * sizeof(float), c->stream);
     (void)hipStreamSynchronize(c->stream);
@@ -392,6 +515,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->tab0.release(); c->tab1.release();
+    c->meta_i.release(); c->meta_j.release(); c->row_cnt.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
     c->aU_m.release(); c->aU_v.release(); c->aV_m.release(); c->aV_v.release();
@@ -664,7 +788,6 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     if (!c || !c->have_factors || !c->have_inter) return fail(YUE_ERR_ARG, "yue_bpr_epoch: upload factors and interactions first");
     if (round_events < 0) return fail(YUE_ERR_ARG, "yue_bpr_epoch: round_events must be positive (or 0 for the device's default)");
     HIPCHK(hipSetDevice(c->device));
-    if (round_events == 0) { const int rc0 = default_round_events(c, &round_events); if (rc0) return rc0; }
     yue::TrainArgs a = make_args(c, lr, regU, regI);
     a.seed = seed + 0x632BE59BD9B4E019ull * (uint64_t)c->rank;   // independent stream per item shard
     a.epoch = epoch;
@@ -680,11 +803,13 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     // users' rows of P and dP only; item rows are rank-local).  The block width comes from job-wide counts:
     // the same blocks on every rank.
     std::vector<int64_t> bounds;
-    double etot = (double)E;
+    double tot[2] = {(double)E, (double)c->n};            // job-wide events and item rows
     if (c->comm) {
-        if ((rc = yue_allreduce_f64(c, &etot, 1))) return rc;
+        if ((rc = yue_allreduce_f64(c, tot, 2))) return rc;
         if ((rc = zero_scalars(c))) return rc;            // the all-reduce used the scalar scratch
     }
+    const double etot = tot[0];
+    if (round_events == 0 && (rc = default_round_events(c, tot[1] / c->nranks, &round_events))) return rc;
     int64_t ub = 1, group = 1;
     if ((rc = yue_epoch_plan(c->m, c->k, round_events, etot, c->nranks, &ub, &group, nullptr))) return rc;
     std::vector<int64_t> ublock;
@@ -709,7 +834,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->comm_stream, c->P.p, c->dP.p, first, count);
         return YUE_OK;
     };
-    if ((rc = run_rounds(c, a, bounds, 0, after))) { reset_round_state(c); return rc; }
+    if ((rc = run_rounds(c, a, bounds, 0, after, meta_path_fits(c)))) { reset_round_state(c); return rc; }
     // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
@@ -733,7 +858,13 @@ int yue_epoch_plan(int64_t m, int k, int64_t round_events, double events_total, 
 int yue_default_round_events(yue_ctx *c, int64_t *out) {
     if (!c || !c->have_factors || !out) return fail(YUE_ERR_ARG, "yue_default_round_events: upload factors first (the value depends on k)");
     HIPCHK(hipSetDevice(c->device));
-    return default_round_events(c, out);
+    double n_rows = (double)c->n;
+    if (c->comm) {                                         // collective on a communicator: every rank gets the same value
+        const int rc = yue_allreduce_f64(c, &n_rows, 1);
+        if (rc) return rc;
+        n_rows /= c->nranks;
+    }
+    return default_round_events(c, n_rows, out);
 }
 
 int yue_set_kernel_timing(yue_ctx *c, int stride) {
@@ -779,12 +910,31 @@ int yue_get_scan_work(yue_ctx *c, int64_t *tiles_scored, int64_t *tiles_total) {
     return YUE_OK;
 }
 
+int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
+    if (!c || !name || !value) return fail(YUE_ERR_ARG, "yue_get_option: null argument");
+    const std::string key(name);
+    if (key == "scan_f32") *value = c->opt_scan_f32;
+    else if (key == "topn_true") *value = c->opt_topn_true;
+    else if (key == "round_stage") *value = c->opt_round_stage;
+    else if (key == "round_meta") *value = c->opt_round_meta;
+    else if (key == "round_fold") *value = c->opt_round_fold;
+    else if (key == "fold_blocks") *value = c->opt_fold_blocks;
+    else if (key == "round_tpw") *value = c->opt_round_tpw;
+    // which kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_m (retire inside), 2 k_round_m + k_round_fold
+    else if (key == "round_path") *value = fold_path(c) ? 2 : meta_path_fits(c) ? 1 : 0;
+    else return fail(YUE_ERR_ARG, "yue_get_option: unknown option " + key);
+    return YUE_OK;
+}
+
 int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail(YUE_ERR_ARG, "yue_set_option: null argument");
     const std::string key(name);
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
+    if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
+    if (key == "round_fold") { c->opt_round_fold = value != 0; return YUE_OK; }
+    if (key == "fold_blocks") { if (value < 1 || value > 65536) return fail(YUE_ERR_ARG, "yue_set_option: fold_blocks out of range"); c->opt_fold_blocks = (int)value; return YUE_OK; }
 #ifdef YUE_STAMPS
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
 #endif

@@ -12,7 +12,7 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
   bpr.hip=-mode epoch -round auto -seed 1
                                         throughput mode: counter-based sampler on the device,
                                         S-round semantics; -round N fixes the round size
-                                        (auto = the device's default, 49,152 events on MI355X at k=128).
+                                        (auto = the device's default: yue_default_round_events, 172,032 events on MI355X for BASELINE config 3).
   bpr.hip=-mode adam                    the reference's LIVE path (BPR.py:65-129, a TensorFlow-1 graph): every "iteration" is one
                                         minibatch of 512 random training events x 100 rejection-sampled negatives (next_batch,
                                         :65-81, same NumPy / random calls), loss = sum softplus(-x) + regU * l2 terms, Adam(lRate)
