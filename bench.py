@@ -101,11 +101,8 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
 
 def round_kernel_label(dev, k):
     kr = 1 if k <= 64 else 2 if k <= 128 else 4
-    path = dev.get_option('round_path')
-    if path == 2:
+    if dev.get_option('round_path') == 1:
         return 'k_round_m<KR=%d> + k_round_fold<KR=%d> (one round: update launch on the pre-pass metadata + rewrite of its contended rows)' % (kr, kr)
-    if path == 1:
-        return 'k_round_m<KR=%d> (update on the pre-pass metadata, contended rows finished by their last toucher)' % kr
     return 'k_round<KR=%d> (update + touch tickets of the next round)' % kr
 
 

@@ -160,20 +160,20 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
 /* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
  *   "round_tpw" events per wave in the training round kernel: 0 = default (16 for k <= 64, 8 for k <= 128, else 4), 2, 4, 8, 16 (k <= 64 only)
- *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in
- *               staging rows (summed in event / ticket order when the row is rewritten);
- *               0: every contended row goes through float atomics
+ *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in staging rows,
+ *               summed in ticket / event order when the row is rewritten; 2..4: that bound chosen explicitly (epoch
+ *               path); 0: every contended row goes through float atomics
  *   "round_meta" 1 (default): yue_bpr_epoch takes the touch metadata of all rounds from one pre-pass per epoch
- *               (k_round_meta; item shards of up to 454,656 rows); 0: touches are counted inside the round launches (k_round)
- *   "round_fold" 1 (default, with round_meta): a round's contended rows are rewritten by a fold launch behind its update
- *               launch; 0: inside the update launch by their last toucher.  Also moves yue_default_round_events.
+ *               (k_round_meta), round launches without a retire phase (k_round_m) and a fold launch behind each
+ *               (k_round_fold) -- item shards of up to 454,656 rows; 0: touches counted and contended rows finished
+ *               inside the round launches (k_round, the kernel of yue_bpr_rounds).  Also moves yue_default_round_events.
  *   "fold_blocks" workgroups of the fold launch (default 1536)
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
  *               the reference's order-dependent overwrite-scan */
 int yue_set_option(yue_ctx *ctx, const char *name, int64_t value);
-/* Reads an option back; "round_path" = the kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_m with the
- * retire phase inside, 2 k_round_m + k_round_fold. */
+/* Reads an option back; "round_path" = the kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round,
+ * 1 k_round_meta + k_round_m + k_round_fold. */
 int yue_get_option(yue_ctx *ctx, const char *name, int64_t *value);
 
 /*

@@ -202,26 +202,26 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
     rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     j = orc.sample_counter(9, 0, ev_u, n, data['indptr'], data['indices'])
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
-    # round_meta: touch metadata from the per-epoch pre-pass (default) vs counted inside the round launches;
-    # round_fold (with round_meta): contended rows rewritten by a fold launch behind every round (default) vs by their last toucher
-    for tpw, stage, meta, fold in [(0, 1, 1, 1), (0, 0, 1, 1), (4, 1, 1, 1), (2, 0, 1, 1), (0, 1, 1, 0), (0, 0, 1, 0), (4, 1, 1, 0), (0, 1, 0, 0), (0, 0, 0, 0), (4, 1, 0, 0)]:
+    # (with round_meta 1 also 2..4: staged up to that many touches per row);
+    # round_meta: touch metadata from the per-epoch pre-pass + fold launches (default) vs touches counted and contended
+    # rows finished inside the round launches
+    for tpw, stage, meta in [(0, 1, 1), (0, 0, 1), (4, 1, 1), (2, 0, 1), (0, 2, 1), (8, 3, 1), (0, 1, 0), (0, 0, 0), (4, 1, 0)]:
         dev = Device(0, raise_errors=True)
         dev.set_option('round_tpw', tpw)
         dev.set_option('round_stage', stage)
         dev.set_option('round_meta', meta)
-        dev.set_option('round_fold', fold)
         dev.set_factors(P0, Q0)
         dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
         nll, _, _ = dev.bpr_epoch(9, 0, W, 0.02, 0.01, 0.01)
         P, Q = dev.get_factors()
         dev.close()
-        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (tpw, stage, meta, fold)
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (tpw, stage, meta)
 
 
 def test_epoch_metadata_pre_pass_over_several_item_ranges(orc):
     # n above one LDS range of the pre-pass (37,888 item rows): three ranges per round, staging blocks of one round handed
     # out by several work items; a popular head (rows with hundreds of touches per round -> float atomics), rows with 2..4
-    # touches (staged) and single touches side by side.  Both counting paths against the oracle.
+    # touches (staged) and single touches side by side.  Both paths against the oracle.
     from yue_amd._shim import Device
     m, n, d, k, W = 12000, 100000, 40, 32, 16384
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=5)
@@ -233,18 +233,17 @@ def test_epoch_metadata_pre_pass_over_several_item_ranges(orc):
         ref.append(orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.03, 0.01, 0.01))
     touched = np.bincount(np.concatenate([data['ev_i'][:W], j[:W]]), minlength=n)
     assert (touched == 1).sum() > 1000 and ((touched >= 2) & (touched <= 4)).sum() > 1000 and (touched > 4).sum() > 30
-    for meta, fold in ((1, 1), (1, 0), (0, 0)):
+    for meta in (1, 0):
         dev = Device(0, raise_errors=True)
         dev.set_option('round_meta', meta)
-        dev.set_option('round_fold', fold)
         dev.set_factors(P0, Q0)
         dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
         for epoch in range(2):
             nll, _, _ = dev.bpr_epoch(13, epoch, W, 0.03, 0.01, 0.01)
-            assert abs(nll - ref[epoch]) <= 1e-9 * abs(ref[epoch]), (meta, fold, epoch)
+            assert abs(nll - ref[epoch]) <= 1e-9 * abs(ref[epoch]), (meta, epoch)
         P, Q = dev.get_factors()
         dev.close()
-        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (meta, fold)
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, meta
 
 
 def test_default_round_size_is_one_resident_wave_set(orc):

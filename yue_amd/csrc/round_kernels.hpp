@@ -1,27 +1,55 @@
-// The epoch path's S-round kernels (round 2): the touch metadata of ALL rounds of an epoch comes from one pre-pass
-// (k_round_meta: LDS histograms, no global atomics), the round kernel (k_round_m) only consumes it.  Same semantics as
-// k_round (train_kernels.hpp) -- what changed is who counts:
-//   k_round    every event takes 2 returning 64-bit device atomics for the NEXT round's tickets, publishes its staging slot
-//              in a per-item table, resets its counter word, and a last toucher reads the table back and sorts the slots;
-//   k_round_m  reads 8 bytes of metadata per event; a contended row's staged differences lie in consecutive staging rows
-//              (base + ticket), so its last toucher needs no table and no sort; the last-arriver count is a 32-bit
-//              count-up word per item row that the last toucher clears.
-// Per event the launch loses 2 returning atomics, ~1.2 scattered 8-byte stores and, per contended touch, one scattered
-// 4-byte store and one 16-byte load.  With the list of a round's contended rows known up front, their rewrite can also
-// leave the launch altogether (k_round_fold).
+// The epoch path's S-round kernels (round 2).  Same semantics as k_round (train_kernels.hpp) -- what
+// changed is who counts the touches of a round and who finishes its contended rows:
+//   k_round        every event takes 2 returning 64-bit device atomics for the NEXT round's tickets, publishes its staging
+//                  slot in a per-item table and resets its counter word; a contended row is finished inside the launch by
+//                  its last toucher (drain own stores, count down, read the table, sort the slots, rewrite): the waves of
+//                  a launch wait for each other, a launch is one wave generation;
+//   k_round_meta   ONE pre-pass per epoch over all rounds: per (round, item range) an LDS histogram of the round's touches,
+//                  a prefix sum that lays the contended rows' staging blocks out behind each other, 8 bytes of metadata per
+//                  event and the list of the round's contended rows -- no global atomics;
+//   k_round_m      reads the metadata, gathers, updates, stores (in place / to the touch's staging row base + ticket / float
+//                  atomics for hot rows) and ends: no wave waits for another, a launch may be several wave generations;
+//   k_round_fold   the next launch on the stream -- the kernel boundary is the synchronisation -- rewrites the round's
+//                  contended rows from the list: row += its block of staged differences in ticket order.
 #pragma once
 #include "train_kernels.hpp"
 
+// timing-only ablations of diagnostic builds (results wrong by construction; never defined in the product build)
+#ifdef YUE_ABL_NO_STAGE
+#define YUE_M_STAGE(val, rs, vo, so) asm volatile("" :: "v"(val))
+#else
+#define YUE_M_STAGE(val, rs, vo, so) YUE_BSTORE(val, rs, vo, so)
+#endif
+#ifdef YUE_ABL_NO_HOT
+#define YUE_M_HOT(val, rs, vo, so) asm volatile("" :: "v"(val))
+#else
+#define YUE_M_HOT(val, rs, vo, so) YUE_BATOMIC(val, rs, vo, so)
+#endif
+#ifdef YUE_ABL_NO_INPLACE
+#define YUE_M_INPLACE(val, rs, vo, so) asm volatile("" :: "v"(val))
+#else
+#define YUE_M_INPLACE(val, rs, vo, so) YUE_BSTORE(val, rs, vo, so)
+#endif
+#ifdef YUE_ABL_NO_DP
+#define YUE_M_DP(val, rs, vo, so) asm volatile("" :: "v"(val))
+#else
+#define YUE_M_DP(val, rs, vo, so) YUE_BATOMIC(val, rs, vo, so)
+#endif
+
 namespace yue {
 
-// Metadata word of one touch (event's positive or negative item row) in its round:
-//   bits 0..2   class: 0 no touch (the sampler gave up on the event), 1 the round's only touch of the row,
-//               2..kStageMax touches -> staged, 5 hotter -> float atomics into dQ
-//   bits 3..5   staged: this touch's ticket on its row (0 .. class - 1)
-//   bits 6..31  staged: first staging row of the row's block (the block is `class` consecutive rows);
+// Metadata word of one touch (an event's positive or negative item row) in its round:
+//   bits 0..3   class: 0 no touch (the sampler gave up on the event), 1 the round's only touch of the row,
+//               2..kMetaStageMax touches -> staged, kMetaHot hotter -> float atomics into dQ
+//   bits 4..6   staged: this touch's ticket on its row (0 .. class - 1; room for blocks of up to 8 rows)
+//   bits 7..31  staged: first staging row of the row's block (the block is `class` consecutive rows);
 //               hot: the row's number of touches in the round
-constexpr uint32_t kMetaHot = 5u;
-constexpr int kMetaUnroll = 24;   // events per thread and step of k_round_meta's two sweeps (their loads are in flight together)
+constexpr uint32_t kMetaStageMax = 4u;   // measured on C3: staging rows with 5..8 touches too is slower (34.0 vs 33.2 ms/epoch)
+constexpr uint32_t kMetaHot = 15u;
+constexpr int kMetaUnroll = 8;       // events per thread and step of k_round_meta's two sweeps (their loads are in flight together)
+__host__ __device__ inline uint32_t meta_class(uint32_t w) { return w & 15u; }
+__host__ __device__ inline uint32_t meta_ticket(uint32_t w) { return (w >> 4) & 7u; }
+__host__ __device__ inline uint32_t meta_payload(uint32_t w) { return w >> 7; }
 
 struct MetaArgs {
     const int32_t *ev_i, *ev_j;
@@ -31,7 +59,7 @@ struct MetaArgs {
     int32_t range;               // item rows per work item (one LDS word each)
     int32_t G;                   // ranges: ceil(n / range)
     int32_t chunk;               // LDS words per thread in the block scan (odd: conflict-free strides)
-    uint32_t stage_max;          // kStageMax, or 1 when the call runs without staging rows
+    uint32_t stage_max;          // rows with 2..stage_max touches are staged (<= kMetaStageMax; 1: no staging rows in this call)
     uint32_t *meta_i, *meta_j;   // [events]
     // [R] per round, zeroed before the launch: low half = staging rows handed out, high half = contended rows listed
     unsigned long long *round_rows;
@@ -44,9 +72,10 @@ struct MetaArgs {
 __host__ __device__ inline int64_t fold_base(int64_t e0, int64_t r) { return (e0 + 4 * r + 3) & ~(int64_t)3; }
 
 // One work item = (round, item range): count the round's touches of the range's rows in LDS, lay the contended rows'
-// staging blocks out behind each other (prefix sum over the range, the range's base from one atomic per work item), then
-// hand every touch its class / ticket / block.  A work item reads the round's (i, j) twice; ranges of one round run on
-// different CUs.
+// staging blocks out behind each other (prefix sum over the range, the range's base from one atomic per work item), list
+// the contended rows, then hand every touch its class / ticket / block.  A work item reads the round's (i, j) twice; ranges
+// of one round run on different CUs.  Tickets follow the order in which the LDS serves the touches, not the event order:
+// the sum of a row's staged differences is taken in ticket order (any order is within the fp32 tolerance of the oracle's).
 __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
     extern __shared__ uint32_t slots[];
     __shared__ unsigned long long wsum[16];
@@ -104,7 +133,7 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
             if (s < width) {
                 const uint32_t c = slots[s];
                 if (c >= 2u) {
-                    const uint32_t wd = c <= a.stage_max ? (c | ((uint32_t)run << 6)) : (kMetaHot | (c << 6));
+                    const uint32_t wd = c <= a.stage_max ? (c | ((uint32_t)run << 7)) : (kMetaHot | (c << 7));
                     slots[s] = wd;
                     fold[run >> 32] = make_uint2((uint32_t)(lo + s), wd);
                     run += (1ull << 32) + (c <= a.stage_max ? c : 0u);
@@ -124,13 +153,15 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
                 const int64_t e = eb + 1024 * q;
                 if (vj[q] >= 0) {
                     const uint32_t si = (uint32_t)(vi[q] - lo), sj = (uint32_t)(vj[q] - lo);
+                    // a staged row's word hands out the tickets: the adds of its `class` touches leave the fields
+                    // a reader needs intact (the last one may carry into the block field, nobody reads it afterwards)
                     if (si < (uint32_t)width) {
-                        const uint32_t wd = slots[si], cl = wd & 7u;
-                        a.meta_i[e] = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[si], 8u) : wd;
+                        const uint32_t wd = slots[si], cl = meta_class(wd);
+                        a.meta_i[e] = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[si], 16u) : wd;
                     }
                     if (sj < (uint32_t)width) {
-                        const uint32_t wd = slots[sj], cl = wd & 7u;
-                        a.meta_j[e] = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[sj], 8u) : wd;
+                        const uint32_t wd = slots[sj], cl = meta_class(wd);
+                        a.meta_j[e] = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[sj], 16u) : wd;
                     }
                 } else if (g == 0 && e < e1) {
                     a.meta_i[e] = 0u; a.meta_j[e] = 0u;
@@ -143,19 +174,15 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
 
 struct RoundMArgs {
     int64_t e_begin, e_end;      // events updated by this launch
-    uint32_t *row_cnt;           // [n] last-arriver count of a contended item row: counts up, cleared by the last toucher (RETIRE)
-    int staged;                  // 1: the staging rows are in use (the metadata was made with stage_max = kStageMax)
+    int staged;                  // 1: the staging rows are in use (the metadata was made with stage_max > 1)
 };
 
-// The S-round launch on pre-pass metadata.  Update semantics, arithmetic and row stores are those of k_round; user rows
-// always stay in dP (the epoch path applies them per group of rounds).
-//   RETIRE = true   contended rows are finished inside the launch by their last toucher (drain, count, rewrite: k_round's
-//                   protocol on the new metadata);
-//   RETIRE = false  the launch ends behind its stores; the round's contended rows are rewritten by k_round_fold, the next
-//                   launch on the stream -- the kernel boundary is the synchronisation, no wave waits for another.
+// The S-round update launch on pre-pass metadata.  Update semantics, arithmetic and the three kinds of row stores are those
+// of k_round; user rows always stay in dP (the epoch path applies them per group of rounds).  The launch ends behind its
+// stores: the round's contended rows are rewritten by k_round_fold.
 // At most 96 SGPRs: a CU then holds 7 workgroups of this kernel (floor(800 / (96 + 16)); with the 106 the compiler would
 // take it is 6, whatever the register-file arithmetic says -- DESIGN.md section 5); the excess lives in VGPR lanes.
-template <int KR, int TPW, bool RETIRE>
+template <int KR, int TPW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_round_m(TrainArgs a, RoundMArgs ra, const int32_t *__restrict__ evu,
                                                  const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                  const uint32_t *__restrict__ mti, const uint32_t *__restrict__ mtj) {
@@ -175,11 +202,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
         hu[t] = evu[ix]; hi_[t] = evi[ix]; hj[t] = ex ? evj[ix] : -1;
         hmi[t] = ex ? mti[ix] : 0u; hmj[t] = ex ? mtj[ix] : 0u;
     }
-    // lane t keeps event t (the retire phase and the loss work per lane)
-    int i = 0, j = -1;
-    uint32_t mi = 0u, mj = 0u;
+    int j = -1;                                          // lane t keeps the negative of event t (the loss works per lane)
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) if (lane == t) { i = hi_[t]; j = hj[t]; mi = hmi[t]; mj = hmj[t]; }
+    for (int t = 0; t < TPW; ++t) if (lane == t) j = hj[t];
     YUE_STAMP(1, "s_waitcnt lgkmcnt(0)");
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = k * 4u;
@@ -187,6 +212,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
 #pragma unroll
     for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; vo[r] = e < k ? e * 4u : kOobOffset; }
 
+    // users of one batch are neighbours (user-major events): P / dP are addressed relative to the
+    // batch's smallest user id, so the 31-bit byte offsets hold for any number of users
     unsigned u0 = 0xffffffffu;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) if (base + t < ra.e_end && (unsigned)hu[t] < u0) u0 = (unsigned)hu[t];
@@ -245,22 +272,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float c = rdlane(cs, t);
-        const unsigned cli = hmi[t] & 7u, clj = hmj[t] & 7u;
+        const unsigned cli = meta_class(hmi[t]), clj = meta_class(hmj[t]);
         const bool uniq_i = cli == 1u, uniq_j = clj == 1u;
         const bool stg_i = cli < kMetaHot, stg_j = clj < kMetaHot;         // (and not unique: tested second)
-        const unsigned si = ((hmi[t] >> 6) + ((hmi[t] >> 3) & 7u)) * row_bytes;   // my staging rows
-        const unsigned sj = ((hmj[t] >> 6) + ((hmj[t] >> 3) & 7u)) * row_bytes;
+        const unsigned si = (meta_payload(hmi[t]) + meta_ticket(hmi[t])) * row_bytes;   // my staging rows
+        const unsigned sj = (meta_payload(hmj[t]) + meta_ticket(hmj[t])) * row_bytes;
         if (ok[t]) {                                     // wave-uniform
             run_ok = true;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 const Elem o = bpr_elem(p[t][r], qi[t][r], qj[t][r], c, a.ru, a.ri);
-                if (uniq_i) YUE_BSTORE(o.qi2, rsQ, vo[r], oi[t]);
-                else if (stg_i) { if (RETIRE) YUE_BSTORE_SC1(o.qi2 - qi[t][r], rsS, vo[r], si); else YUE_BSTORE(o.qi2 - qi[t][r], rsS, vo[r], si); }
-                else YUE_BATOMIC(o.qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
-                if (uniq_j) YUE_BSTORE(o.qj2, rsQ, vo[r], oj[t]);
-                else if (stg_j) { if (RETIRE) YUE_BSTORE_SC1(o.qj2 - qj[t][r], rsS, vo[r], sj); else YUE_BSTORE(o.qj2 - qj[t][r], rsS, vo[r], sj); }
-                else YUE_BATOMIC(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
+                if (uniq_i) YUE_M_INPLACE(o.qi2, rsQ, vo[r], oi[t]);
+                else if (stg_i) YUE_M_STAGE(o.qi2 - qi[t][r], rsS, vo[r], si);
+                else YUE_M_HOT(o.qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
+                if (uniq_j) YUE_M_INPLACE(o.qj2, rsQ, vo[r], oj[t]);
+                else if (stg_j) YUE_M_STAGE(o.qj2 - qj[t][r], rsS, vo[r], sj);
+                else YUE_M_HOT(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
                 dp[r] += o.p2 - p[t][r];
             }
         }
@@ -270,7 +297,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
         if (last) {
             if (run_ok) {
 #pragma unroll
-                for (int r = 0; r < KR; ++r) YUE_BATOMIC(dp[r], rsdP, vo[r], ou[t]);
+                for (int r = 0; r < KR; ++r) YUE_M_DP(dp[r], rsdP, vo[r], ou[t]);
             }
 #pragma unroll
             for (int r = 0; r < KR; ++r) dp[r] = 0.0f;
@@ -278,131 +305,55 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-
-    // Retire this batch's touches of contended rows.  Every toucher counts the row up once its own stores / adds are
-    // acknowledged; whoever brings the count to the row's number of touches knows every difference of the round has been
-    // written and every toucher has read the row: it sums the block of staged rows in ticket order (or swaps the sum out
-    // of dQ, leaving it zeroed), rewrites the row and clears the count.
     YUE_STAMP(4, "");
-    if (RETIRE) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    YUE_STAMP(5, "");
-    bool last_i = false, last_j = false;
-    if (lane < TPW && j >= 0) {
-        const uint32_t cli = mi & 7u, clj = mj & 7u;
-        if (cli != 1u) last_i = atomicAdd(ra.row_cnt + i, 1u) + 1u == (cli < kMetaHot ? cli : mi >> 6);
-        if (clj != 1u) last_j = atomicAdd(ra.row_cnt + j, 1u) + 1u == (clj < kMetaHot ? clj : mj >> 6);
-    }
-    // winners: bits [0,TPW) = item row i of that lane, [TPW,2*TPW) = row j
-    unsigned long long win = (__ballot(last_i) & ((1ull << TPW) - 1)) | ((__ballot(last_j) & ((1ull << TPW) - 1)) << TPW);
-    YUE_STAMP(6, "s_waitcnt vmcnt(0)");
-    while (win) {
-        // up to four rows per pass: all swaps and row loads are issued before the first store
-        float *xp[4], *dx[4];
-        bool act[4];
-        unsigned nst[4], so[4];                          // staged rows to add (0: the row went through dQ), first of them
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            act[sl] = win != 0;
-            const int b = act[sl] ? __ffsll((long long)win) - 1 : 0;
-            if (act[sl]) win &= win - 1;
-            const int src = b % TPW;
-            const unsigned row = b < TPW ? (unsigned)__builtin_amdgcn_readlane(i, src) : (unsigned)__builtin_amdgcn_readlane(j, src);
-            const unsigned mw = b < TPW ? (unsigned)__builtin_amdgcn_readlane((int)mi, src) : (unsigned)__builtin_amdgcn_readlane((int)mj, src);
-            nst[sl] = act[sl] && (mw & 7u) < kMetaHot ? (mw & 7u) : 0u;
-            so[sl] = (mw >> 6) * row_bytes;
-            const uint64_t o = (uint64_t)row * k;
-            xp[sl] = a.Q + o;
-            dx[sl] = a.dQ + o;
-            if (act[sl] && lane == 0) ra.row_cnt[row] = 0u;                  // every touch retired: clear the count
-        }
-        float d[4][KR], x[4][KR];
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl)
-            if (act[sl]) {
-                if (nst[sl]) {
-                    // every load of the staged bytes is an sc1 load issued after this wave's own count returned;
-                    // rows beyond the block get an out-of-range offset (read 0)
-                    float st[kStageMax][KR];
-#pragma unroll
-                    for (unsigned q = 0; q < kStageMax; ++q)
-#pragma unroll
-                        for (int r = 0; r < KR; ++r)
-                            st[q][r] = YUE_BLOAD_SC1(rsS, q < nst[sl] ? vo[r] : kOobOffset, q < nst[sl] ? so[sl] + q * row_bytes : 0u);
-#pragma unroll
-                    for (int r = 0; r < KR; ++r) {
-                        const unsigned e = 64u * r + lane;
-                        if (e < k) x[sl][r] = xp[sl][e];
-                        float acc = st[0][r];
-#pragma unroll
-                        for (unsigned q = 1; q < kStageMax; ++q) acc = acc + st[q][r];
-                        d[sl][r] = acc;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < KR; ++r) {
-                        const unsigned e = 64u * r + lane;
-                        if (e < k) { d[sl][r] = atomicExch(dx[sl] + e, 0.0f); x[sl][r] = xp[sl][e]; }
-                    }
-                }
-            }
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl)
-            if (act[sl]) {
-#pragma unroll
-                for (int r = 0; r < KR; ++r) {
-                    const unsigned e = 64u * r + lane;
-                    if (e < k) xp[sl][e] = x[sl][r] + d[sl][r];
-                }
-            }
-    }
-    }
-    YUE_STAMP(7, "s_waitcnt vmcnt(0)");
 #pragma unroll
     for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
     if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);
+    YUE_STAMP(7, "s_waitcnt vmcnt(0)");
 }
 
 // Rewrites the contended item rows of one round from the pre-pass's fold list: row += the block of staged differences in
-// ticket order, or += the row of dQ (zeroed again) for a hot row.  A wave takes four consecutive list entries at a time
+// ticket order, or += the row of dQ (zeroed again) for a hot row.  A wave takes EPG consecutive list entries at a time
 // (rows of neighbouring items: their staging blocks lie behind each other), all loads before the first store.
 struct FoldArgs {
-    const uint2 *fold;                     // this round's entries
+    const uint2 *fold;                     // this round's entries (16-byte aligned)
     const unsigned long long *round_rows;  // this round's counters (high half: entries)
     float *Q, *dQ;
     const float *stage;
     int k;
-    uint32_t capacity;                     // entries the round's list area has room for (>= 4)
+    uint32_t capacity;                     // entries the round's list area has room for (a multiple of 4)
 };
 
-template <int KR>
+template <int KR, int EPG>
 __device__ __forceinline__ void fold_group(const FoldArgs &f, int lane, unsigned k, uint32_t nact, const uint2 (&ent)[4]) {
-    // straight-line loads (no wait between the entries): a staged row's block is read as kStageMax rows -- beyond its
-    // touches the first row again, dropped in the sum; a hot row reads its row of dQ; lanes beyond k read element k - 1
-    float x[4][KR], st[4][kStageMax][KR];
+    // straight-line loads (no wait between the entries): the first two rows of a block always (a hot row reads its row of
+    // dQ), rows 2..3 behind a wave-uniform branch on the row's touch count; lanes beyond k read element k - 1
+    float x[EPG][KR], st[EPG][kMetaStageMax][KR];
     unsigned el[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) el[r] = min(64u * r + lane, k - 1u);
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
+    for (int sl = 0; sl < EPG; ++sl) {
         if ((uint32_t)sl >= nact) continue;
-        const uint32_t c = ent[sl].y & 7u;
+        const uint32_t c = meta_class(ent[sl].y);
         const bool hot = c >= kMetaHot;
         const float *row = f.Q + (uint64_t)ent[sl].x * k;
-        const float *src = hot ? f.dQ + (uint64_t)ent[sl].x * k : f.stage + (uint64_t)(ent[sl].y >> 6) * k;
+        const float *src = hot ? f.dQ + (uint64_t)ent[sl].x * k : f.stage + (uint64_t)meta_payload(ent[sl].y) * k;
 #pragma unroll
-        for (unsigned q = 0; q < kStageMax; ++q) {
-            const float *sq = src + (uint64_t)((!hot && q < c) ? q : 0u) * k;
+        for (int r = 0; r < KR; ++r) { st[sl][0][r] = src[el[r]]; if (!hot) st[sl][1][r] = src[(uint64_t)k + el[r]]; }
+        if (!hot && c > 2u) {
 #pragma unroll
-            for (int r = 0; r < KR; ++r) st[sl][q][r] = sq[el[r]];
+            for (unsigned q = 2; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < KR; ++r) st[sl][q][r] = src[(uint64_t)(q < c ? q : 0u) * k + el[r]];
         }
 #pragma unroll
         for (int r = 0; r < KR; ++r) x[sl][r] = row[el[r]];
     }
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
+    for (int sl = 0; sl < EPG; ++sl) {
         if ((uint32_t)sl >= nact) continue;
-        const uint32_t c = ent[sl].y & 7u;
+        const uint32_t c = meta_class(ent[sl].y);
         const bool hot = c >= kMetaHot;
         float *row = f.Q + (uint64_t)ent[sl].x * k;
         float *dr = f.dQ + (uint64_t)ent[sl].x * k;
@@ -411,7 +362,7 @@ __device__ __forceinline__ void fold_group(const FoldArgs &f, int lane, unsigned
             const unsigned e = 64u * r + lane;
             float acc = st[sl][0][r];
 #pragma unroll
-            for (unsigned q = 1; q < kStageMax; ++q) { const float v = (!hot && q < c) ? st[sl][q][r] : 0.0f; acc = acc + v; }
+            for (unsigned q = 1; q < kMetaStageMax; ++q) { const float v = (!hot && q < c) ? st[sl][q][r] : 0.0f; acc = acc + v; }
             if (e < k) { row[e] = x[sl][r] + acc; if (hot) dr[e] = 0.0f; }
         }
     }
@@ -419,14 +370,15 @@ __device__ __forceinline__ void fold_group(const FoldArgs &f, int lane, unsigned
 
 template <int KR>
 __global__ void __launch_bounds__(256) k_round_fold(FoldArgs f) {
+    constexpr int EPG = KR == 4 ? 2 : 4;                // list entries per group (register budget: EPG * 5 * KR row registers)
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t nwaves = gridDim.x * 4u;
     const unsigned k = (unsigned)f.k;
     // The first group's entries are requested together with the round's entry count (one round trip less on a kernel that
-    // is all latency): the list area of a round has room for f.capacity entries (a multiple of 4 by allocation), whatever
-    // they hold is only used below the count.
-    const uint32_t b0 = wave * 4u;
+    // starts with a chain of dependent loads): the list area of a round has room for f.capacity entries, whatever they
+    // hold is only used below the count.
+    const uint32_t b0 = wave * EPG;
     uint2 ent[4];
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     u32x8 ev;
@@ -437,11 +389,11 @@ __global__ void __launch_bounds__(256) k_round_fold(FoldArgs f) {
                  : "=&s"(ev), "=&s"(cntw) : "s"(first), "s"(f.round_rows) : "memory");
     const uint32_t cnt = (uint32_t)(cntw >> 32);
     ent[0] = make_uint2(ev[0], ev[1]); ent[1] = make_uint2(ev[2], ev[3]); ent[2] = make_uint2(ev[4], ev[5]); ent[3] = make_uint2(ev[6], ev[7]);
-    if (b0 < cnt) fold_group<KR>(f, lane, k, min(4u, cnt - b0), ent);
-    for (uint32_t b = b0 + nwaves * 4u; b < cnt; b += nwaves * 4u) {
+    if (b0 < cnt) fold_group<KR, EPG>(f, lane, k, min((uint32_t)EPG, cnt - b0), ent);
+    for (uint32_t b = b0 + nwaves * EPG; b < cnt; b += nwaves * EPG) {
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) ent[sl] = f.fold[b + sl < cnt ? b + sl : b];
-        fold_group<KR>(f, lane, k, min(4u, cnt - b), ent);
+        for (int sl = 0; sl < EPG; ++sl) ent[sl] = f.fold[b + sl < cnt ? b + sl : b];
+        fold_group<KR, EPG>(f, lane, k, min((uint32_t)EPG, cnt - b), ent);
     }
 }
 

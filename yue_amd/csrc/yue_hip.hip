@@ -70,7 +70,7 @@ struct yue_ctx {
     // so that "new row in place" and "new row to my staging row" are the same store with another offset
     bool staged = false;                         // the running call uses the staging rows
     // epoch path: touch metadata of all rounds from one pre-pass (round_kernels.hpp)
-    DevBuf<uint32_t> meta_i, meta_j, row_cnt;
+    DevBuf<uint32_t> meta_i, meta_j;
     DevBuf<unsigned long long> round_rows;
     DevBuf<uint2> fold;
     DevBuf<int64_t> d_bounds;
@@ -99,8 +99,7 @@ struct yue_ctx {
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
-    int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows)
-    int opt_round_fold = 1;              // epoch path with metadata: 1 contended rows rewritten by k_round_fold behind every round launch, 0 inside the launch (last toucher)
+    int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 2..4: rows with up to that many touches are staged (epoch path)
     int opt_fold_blocks = 1536;           // workgroups of k_round_fold
     int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
     // kernel timing
@@ -175,7 +174,7 @@ constexpr int64_t kMetaRangesMax = 12;
 constexpr int64_t kRoundGenerationsMax = 3;
 
 bool meta_path_fits(const yue_ctx *c) { return c->opt_round_meta && c->n <= kMetaRangeMax * kMetaRangesMax; }
-bool fold_path(const yue_ctx *c) { return meta_path_fits(c) && c->opt_round_fold; }
+bool fold_path(const yue_ctx *c) { return meta_path_fits(c); }
 
 // Default round size.
 //   * k_round / k_round_m with the retire phase inside the launch: the events ONE resident set of waves takes (workgroups
@@ -191,7 +190,7 @@ int default_round_events(yue_ctx *c, double n_rows, int64_t *out) {
     int per_cu = 0, cus = 0;
     hipError_t e = hipSuccess;
 #define YUE_OCC(KR_, TPW_) \
-    e = fold ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_m<KR_, TPW_, false>, 256, 0) \
+    e = fold ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_m<KR_, TPW_>, 256, 0) \
              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round<KR_, TPW_>, 256, 0); \
     break;
     switch (kr_of(c->k) * 16 + tpw) {
@@ -269,10 +268,6 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
     const int64_t R = (int64_t)bounds.size() - 1;
     const int64_t E = bounds.back();
     HIPCHK(c->meta_i.resize((size_t)std::max<int64_t>(E, 1))); HIPCHK(c->meta_j.resize((size_t)std::max<int64_t>(E, 1)));
-    if (c->row_cnt.n < (size_t)c->n) {
-        HIPCHK(c->row_cnt.resize((size_t)c->n));
-        HIPCHK(hipMemsetAsync(c->row_cnt.p, 0, c->row_cnt.n * sizeof(uint32_t), c->stream));
-    }
     HIPCHK(c->round_rows.resize((size_t)R)); HIPCHK(c->d_bounds.resize((size_t)R + 1));
     if (c->h_bounds != bounds) {                       // the same blocks epoch after epoch: uploaded once
         HIPCHK(hipStreamSynchronize(c->stream));       // an earlier upload may still read h_bounds
@@ -286,7 +281,7 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
     ma.G = (int32_t)((c->n + kMetaRangeMax - 1) / kMetaRangeMax);
     ma.range = (int32_t)((c->n + ma.G - 1) / ma.G);
     ma.chunk = (ma.range + 1023) / 1024; ma.chunk |= 1;
-    ma.stage_max = c->staged ? yue::kStageMax : 1u;
+    ma.stage_max = !c->staged ? 1u : c->opt_round_stage >= 2 ? (uint32_t)c->opt_round_stage : yue::kMetaStageMax;
     ma.meta_i = c->meta_i.p; ma.meta_j = c->meta_j.p; ma.round_rows = c->round_rows.p; ma.fold = c->fold.p;
     const size_t lds = (size_t)ma.range * sizeof(uint32_t);
     HIPCHK(hipFuncSetAttribute((const void *)yue::k_round_meta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -301,7 +296,7 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
 
 int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t round_index) {
     yue::RoundMArgs ra{};
-    ra.e_begin = e0; ra.e_end = e1; ra.row_cnt = c->row_cnt.p; ra.staged = c->staged ? 1 : 0;
+    ra.e_begin = e0; ra.e_end = e1; ra.staged = c->staged ? 1 : 0;
     const int tpw = tpw_of(c);
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
     const int64_t blocks = (waves + 3) / 4;
@@ -320,10 +315,7 @@ int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e
     const yue::TrainArgs &a = a_in;
 #endif
     const uint32_t *mi = c->meta_i.p, *mj = c->meta_j.p;
-#define YUE_RM(KR_, TPW_) \
-    if (c->opt_round_fold) hipLaunchKernelGGL((yue::k_round_m<KR_, TPW_, false>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); \
-    else hipLaunchKernelGGL((yue::k_round_m<KR_, TPW_, true>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); \
-    break;
+#define YUE_RM(KR_, TPW_) hipLaunchKernelGGL((yue::k_round_m<KR_, TPW_>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); break;
     switch (kr_of(c->k) * 16 + tpw) {
         case 1 * 16 + 8: YUE_RM(1, 8)
         case 1 * 16 + 16: YUE_RM(1, 16)
@@ -336,7 +328,7 @@ int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e
         default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
     }
 #undef YUE_RM
-    if (c->opt_round_fold) {
+    {
         yue::FoldArgs f{};
         f.fold = c->fold.p + yue::fold_base(e0, round_index); f.round_rows = c->round_rows.p + round_index; f.Q = a.Q; f.dQ = a.dQ; f.stage = a.stage; f.k = c->k; f.capacity = (uint32_t)((e1 - e0) & ~(int64_t)3);
         const dim3 fgrid((unsigned)std::min<int64_t>(c->opt_fold_blocks, std::max<int64_t>(1, (e1 - e0 + 15) / 16)));
@@ -425,7 +417,6 @@ void reset_round_state(yue_ctx *c) {
     if (c->cnt1.p) (void)hipMemsetAsync(c->cnt1.p, 0, c->cnt1.n * sizeof(unsigned long long), c->stream);
     if (c->cntp0.p) (void)hipMemsetAsync(c->cntp0.p, 0, c->cntp0.n * sizeof(uint32_t), c->stream);
     if (c->cntp1.p) (void)hipMemsetAsync(c->cntp1.p, 0, c->cntp1.n * sizeof(uint32_t), c->stream);
-    if (c->row_cnt.p) (void)hipMemsetAsync(c->row_cnt.p, 0, c->row_cnt.n * sizeof(uint32_t), c->stream);
     if (c->dP.p) (void)hipMemsetAsync(c->dP.p, 0, c->dP.n * sizeof(float), c->stream);
     if (c->dQ.p) (void)hipMemsetAsync(c->dQ.p, 0, c->dQ.n * sizeof(float), c->stream);
     (void)hipStreamSynchronize(c->stream);
@@ -515,7 +506,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->tab0.release(); c->tab1.release();
-    c->meta_i.release(); c->meta_j.release(); c->row_cnt.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release();
+    c->meta_i.release(); c->meta_j.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
     c->aU_m.release(); c->aU_v.release(); c->aV_m.release(); c->aV_v.release();
@@ -917,11 +908,10 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "topn_true") *value = c->opt_topn_true;
     else if (key == "round_stage") *value = c->opt_round_stage;
     else if (key == "round_meta") *value = c->opt_round_meta;
-    else if (key == "round_fold") *value = c->opt_round_fold;
     else if (key == "fold_blocks") *value = c->opt_fold_blocks;
     else if (key == "round_tpw") *value = c->opt_round_tpw;
-    // which kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_m (retire inside), 2 k_round_m + k_round_fold
-    else if (key == "round_path") *value = fold_path(c) ? 2 : meta_path_fits(c) ? 1 : 0;
+    // which kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_meta + k_round_m + k_round_fold
+    else if (key == "round_path") *value = fold_path(c) ? 1 : 0;
     else return fail(YUE_ERR_ARG, "yue_get_option: unknown option " + key);
     return YUE_OK;
 }
@@ -931,9 +921,11 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     const std::string key(name);
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
-    if (key == "round_stage") { c->opt_round_stage = value != 0; return YUE_OK; }
+    if (key == "round_stage") {
+        if (value < 0 || value > (int64_t)yue::kMetaStageMax) return fail(YUE_ERR_ARG, "yue_set_option: round_stage must be 0, 1 or 2..4");
+        c->opt_round_stage = (int)value; return YUE_OK;
+    }
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
-    if (key == "round_fold") { c->opt_round_fold = value != 0; return YUE_OK; }
     if (key == "fold_blocks") { if (value < 1 || value > 65536) return fail(YUE_ERR_ARG, "yue_set_option: fold_blocks out of range"); c->opt_fold_blocks = (int)value; return YUE_OK; }
 #ifdef YUE_STAMPS
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
