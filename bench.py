@@ -196,6 +196,9 @@ def bench_scoring(args, cp):
     users = np.arange(lo, hi, dtype=np.int32)
     if args.scan_f32:
         dev.set_option('scan_f32', 1)
+    for kv in args.opt:
+        name, value = kv.split('=')
+        dev.set_option(name, int(value))
     for _ in range(args.warmup):
         dev.topn_scan(users, N)
     cp.barrier()

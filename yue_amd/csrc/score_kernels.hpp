@@ -299,25 +299,47 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline size_t scan_bf16_lds_bytes(int k, int N) {
-    const size_t tile = 2u * kScanTile * (k + 4) * sizeof(float);
-    const size_t state = (size_t)kScanWaves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
+// T = tiles whose survivors are re-scored together (the fp32 tiles live in a ring of T + 1 LDS buffers), WAVES = waves
+// (of 32 users) per workgroup.  Per phase of the re-score pipeline a wave runs ONE chain for every user that still has a
+// survivor: the phases of a batch number max over the wave's users of their survivors (+ 1); with the survivors of T
+// tiles pooled that maximum grows far slower than T (measured on C5, random factors: ~3 phases per tile at T = 1).
+// Exchange between the two lanes (r, 0) / (r, 1) = lanes r and r + 32 of a user: v_permlane32_swap (gfx950) instead of a
+// ds_bpermute round trip through the LDS.  lo: every lane gets the value of lane (lane & 31); hi: of lane 32 + (lane & 31).
+__device__ __forceinline__ void half_bcast(uint32_t v, uint32_t &lo, uint32_t &hi) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    lo = sw[0]; hi = sw[1];
+}
+__device__ __forceinline__ uint32_t lo_bcast(uint32_t v) { uint32_t lo, hi; half_bcast(v, lo, hi); return lo; }
+__device__ __forceinline__ uint32_t hi_bcast(uint32_t v) { uint32_t lo, hi; half_bcast(v, lo, hi); return hi; }
+__device__ __forceinline__ float lo_bcast(float v) { return __builtin_bit_cast(float, lo_bcast(__builtin_bit_cast(uint32_t, v))); }
+__device__ __forceinline__ float hi_bcast(float v) { return __builtin_bit_cast(float, hi_bcast(__builtin_bit_cast(uint32_t, v))); }
+
+constexpr int kScanBfPad = 8;        // bf16 elements of padding per tile row: rows 16 lanes apart fall on different banks
+__host__ __device__ inline size_t scan_bf16_lds_bytes(int k, int N, int T, int waves) {
+    const size_t tile = (size_t)(T + 1) * kScanTile * (k + 4) * sizeof(float) + 2u * kScanTile * (k + kScanBfPad) * 2u;
+    const size_t state = (size_t)waves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
     return tile + state;
 }
 
-template <int K16>
-__global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
+template <int K16, int T, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf16(ScanArgs a) {
+    static_assert(T == 1 || T == 2 || T == 4, "survivor words: one 32-bit mask per tile, at most 128 bits");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int K = 16 * K16, LD = K + 4;
+    constexpr int K = 16 * K16, LD = K + 4, R = T + 1, NT = 64 * WAVES;
     const int N = a.N, NS = scan_ns(N);
-    float *tile = reinterpret_cast<float *>(lds_raw);                       // [2][32][LD] fp32
-    float *st_a_all = tile + 2 * kScanTile * LD;
-    int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + kScanWaves * 32 * NS);
+    // Two copies of an item tile: fp32 rows in a ring of R buffers (read by the exact re-score chains of the batch), and the
+    // same rows rounded to bf16 in a double buffer -- converted ONCE per workgroup when the tile is committed; every wave
+    // reads its MFMA operands from there (half the LDS bytes of the fp32 rows, no conversion in the loop).
+    constexpr int LDB = K + kScanBfPad;
+    float *tile = reinterpret_cast<float *>(lds_raw);                       // [R][32][LD] fp32
+    __bf16 *btile = reinterpret_cast<__bf16 *>(tile + R * kScanTile * LD);  // [2][32][LDB] bf16
+    float *st_a_all = reinterpret_cast<float *>(btile + 2 * kScanTile * LDB);
+    int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + WAVES * 32 * NS);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    const int64_t upos = (int64_t)blockIdx.x * (kScanWaves * 32) + w * 32 + r;
+    const int64_t upos = (int64_t)blockIdx.x * (WAVES * 32) + w * 32 + r;
     const bool uvalid = upos < a.nu;
     const int32_t uid = a.users[uvalid ? upos : 0];
     const float *prow = a.P + (int64_t)uid * K;
@@ -348,10 +370,13 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
     const float pn = mu * (128.0f * 1.0001f / 1.01f);
 
     // item tiles: global -> registers (one tile ahead) -> LDS, float4 granularity
-    constexpr int PF4 = (kScanTile * K / 4 + 255) / 256;
-    int lds_off[PF4];
+    constexpr int PF4 = (kScanTile * K / 4 + NT - 1) / NT;
+    int lds_off[PF4], ldb_off[PF4];
 #pragma unroll
-    for (int q = 0; q < PF4; ++q) { const int el = (tid + 256 * q) * 4; const int row = el / K; lds_off[q] = row * LD + (el - row * K); }
+    for (int q = 0; q < PF4; ++q) {
+        const int el = (tid + NT * q) * 4; const int row = el / K;
+        lds_off[q] = row * LD + (el - row * K); ldb_off[q] = row * LDB + (el - row * K);
+    }
     f32x4 pre[PF4];
     float nu_next = 0.0f;
     auto fetch = [&](int64_t it0) {
@@ -359,15 +384,24 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         const float *src = a.Q + it0 * K;
 #pragma unroll
         for (int q = 0; q < PF4; ++q) {
-            const int el = (tid + 256 * q) * 4;
+            const int el = (tid + NT * q) * 4;
             pre[q] = (el < kScanTile * K && el < limit) ? *reinterpret_cast<const f32x4 *>(src + el) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         nu_next = a.tile_norm_max[it0 / kScanTile];             // largest ||Q_i|| of the tile (wave-uniform)
     };
-    auto commit = [&](int buf) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    auto commit = [&](int buf, int bbuf) {
         float *dst = tile + buf * kScanTile * LD;
+        __bf16 *bdst = btile + bbuf * kScanTile * LDB;
 #pragma unroll
-        for (int q = 0; q < PF4; ++q) if ((tid + 256 * q) * 4 < kScanTile * K) *reinterpret_cast<f32x4 *>(dst + lds_off[q]) = pre[q];
+        for (int q = 0; q < PF4; ++q)
+            if ((tid + NT * q) * 4 < kScanTile * K) {
+                *reinterpret_cast<f32x4 *>(dst + lds_off[q]) = pre[q];
+                bf16x4 b;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) b[jj] = (__bf16)pre[q][jj];
+                *reinterpret_cast<bf16x4 *>(bdst + ldb_off[q]) = b;
+            }
     };
 
     ScanState S;
@@ -385,17 +419,19 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         mcur = a.mask_ptr[mrow]; mend = a.mask_ptr[mrow + 1];
         if (mcur < mend) mnext = a.mask_idx[mcur];
     }
+    // survivors of the running batch of T tiles (lanes (r,0)): bit 32 * (tile in batch) + column
+    unsigned long long cand_lo = 0ull, cand_hi = 0ull;
 
     const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
     fetch(0);
-    commit(0);
+    commit(0, 0);
     float nu = nu_next;
     __syncthreads();
 
     for (int64_t t = 0; t < ntiles; ++t) {
-        const int cur = (int)(t & 1);
+        const int tb_in = (int)(t % T);                        // position of this tile in its batch
         const int64_t it0 = t * kScanTile;
-        const float *tb = tile + cur * kScanTile * LD;
+        const __bf16 *tbb = btile + (int)(t & 1) * kScanTile * LDB;
         if (t + 1 < ntiles) fetch(it0 + kScanTile);
         // can any user of this wave still change in this tile?  (mask cursors of skipped tiles catch up in the next scanned one)
         const bool settled = !(h == 0 && uvalid) || (S.cnt == N && pn * nu <= S.thr);
@@ -408,13 +444,10 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-        const float *irow = tb + r * LD + 8 * h;
+        const __bf16 *irow = tbb + r * LDB + 8 * h;
 #pragma unroll
         for (int s = 0; s < K16; ++s) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(irow + 16 * s), b1 = *reinterpret_cast<const f32x4 *>(irow + 16 * s + 4);
-            bf16x8 itf;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { itf[jj] = (__bf16)b0[jj]; itf[jj + 4] = (__bf16)b1[jj]; }
+            const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[s], acc, 0, 0, 0);
         }
 
@@ -424,11 +457,10 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) pmask |= (bar < acc[q] ? 1u : 0u) << ((q & 3) + 8 * (q >> 2));
         pmask <<= 4 * h;                                       // rows of lane (r,1) are shifted by 4
-        pmask |= (uint32_t)__shfl_xor((int)pmask, 32);         // both lanes of a user now hold all 32 columns
+        { uint32_t plo, phi; half_bcast(pmask, plo, phi); pmask = plo | phi; }    // both lanes of a user now hold all 32 columns
         const int64_t left = a.n - it0;
         if (left < kScanTile) pmask &= (1u << (uint32_t)left) - 1u;
 
-        uint32_t cand = 0u;
         if (h == 0 && uvalid) {
             uint32_t mb = 0u;
             while (mnext < it0 + kScanTile) {
@@ -436,47 +468,59 @@ __global__ void __launch_bounds__(256, 2) k_topn_scan_bf16(ScanArgs a) {
                 ++mcur;
                 mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
             }
-            cand = pmask & ~mb;
+#if defined(YUE_SCAN_ABL) && YUE_SCAN_ABL == 1       // timing-only ablation of a diagnostic build: no survivors after the seeds
+            const unsigned long long cd = S.cnt < N ? (unsigned long long)(pmask & ~mb) : 0ull;
+#else
+            const unsigned long long cd = (unsigned long long)(pmask & ~mb);
+#endif
+            if (tb_in < 2) cand_lo |= cd << (32 * (tb_in & 1)); else cand_hi |= cd << (32 * (tb_in & 1));
         }
-        // Survivors.  Exact score = k-ascending fp32 fma chain (== v_mfma_f32_32x32x2_f32, == oracle),
-        // run as a two-stage pipeline over the user's two lanes: in every phase lane (r,0) takes the
-        // user's next survivor through elements [0,K/2) while lane (r,1) finishes the previous one
-        // through [K/2,K) from the partial handed over -- one chain execution per phase for the whole
-        // wave, survivors complete in ascending item order.
-        int c_prev = -1;
-        float s_prev = 0.0f;
-        for (;;) {
-            const int c_pop = (h == 0 && cand) ? __ffs(cand) - 1 : -1;
-            const int c_from = __shfl(c_prev, r);
-            const float s_from = __shfl(s_prev, r);
-            const int c_cur = h ? c_from : c_pop;
-            float sc = h ? s_from : 0.0f;
-            if (__ballot(c_cur >= 0) == 0ull) break;
-            if (c_pop >= 0) cand &= cand - 1;
-            if (c_cur >= 0) {
-                const float *qrow = tb + c_cur * LD + h * KH;
+        }
+        // Survivors of the batch, once its last tile is in (or the scan ends).  Exact score = k-ascending fp32 fma chain
+        // (== v_mfma_f32_32x32x2_f32, == oracle), run as a two-stage pipeline over the user's two lanes: in every phase
+        // lane (r,0) takes the user's next survivor through elements [0,K/2) while lane (r,1) finishes the previous one
+        // through [K/2,K) from the partial handed over -- one chain execution per phase for the whole wave, survivors
+        // complete in ascending item order.  Until then the thresholds of the filter are those of the previous batch: a
+        // lower threshold only lets more candidates through, the state machine re-checks with the exact score.
+        if (tb_in == T - 1 || t + 1 == ntiles) {
+            const int64_t tfirst = t - tb_in;                  // first tile of the batch
+            const int64_t it_batch = tfirst * kScanTile;
+            int c_prev = -1;
+            float s_prev = 0.0f;
+            for (;;) {
+                int c_pop = -1;
+                if (h == 0) { if (cand_lo) c_pop = __ffsll((long long)cand_lo) - 1; else if (cand_hi) c_pop = 64 + __ffsll((long long)cand_hi) - 1; }
+                const int c_from = (int)lo_bcast((uint32_t)c_prev);
+                const float s_from = lo_bcast(s_prev);
+                const int c_cur = h ? c_from : c_pop;
+                float sc = h ? s_from : 0.0f;
+                if (__ballot(c_cur >= 0) == 0ull) break;
+                if (c_pop >= 0) { if (c_pop < 64) cand_lo &= cand_lo - 1; else cand_hi &= cand_hi - 1; }
+                if (c_cur >= 0) {
+                    const int slot = (int)((tfirst + (c_cur >> 5)) % R);
+                    const float *qrow = tile + (slot * kScanTile + (c_cur & 31)) * LD + h * KH;
 #pragma unroll
-                for (int e = 0; e < KH; e += 4) {
-                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
-                    sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
-                    sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
+                    for (int e = 0; e < KH; e += 4) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
+                        sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
+                        sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
+                    }
                 }
+                const float s_done = hi_bcast(sc);                // finished scores travel back to lane (r,0)
+                const int c_done = (int)hi_bcast((uint32_t)c_cur);
+                if (h == 0 && c_done >= 0) {
+                    ++rescored;
+                    if (!(S.cnt == N && !(S.thr < s_done))) scan_push(S, N, s_done, (int32_t)(it_batch + c_done), a.true_topn);
+                }
+                c_prev = c_cur;
+                s_prev = sc;
             }
-            const float s_done = __shfl(sc, r + 32);          // finished scores travel back to lane (r,0)
-            const int c_done = __shfl(c_cur, r + 32);
-            if (h == 0 && c_done >= 0) {
-                ++rescored;
-                if (!(S.cnt == N && !(S.thr < s_done))) scan_push(S, N, s_done, (int32_t)(it0 + c_done), a.true_topn);
-            }
-            c_prev = c_cur;
-            s_prev = sc;
+            thr_lane = lo_bcast(S.thr);                            // lane (r,1) filters with its user's threshold too
         }
-        thr_lane = __shfl(S.thr, r);                           // lane (r,1) filters with its user's threshold too
-        }
-        if (t + 1 < ntiles) commit(cur ^ 1);
+        if (t + 1 < ntiles) commit((int)((t + 1) % R), (int)((t + 1) & 1));
         nu = nu_next;
         if ((t & 15) == 15 && t + 1 < ntiles) {
-            // every 16 tiles: does any user of the workgroup still have a chance in ANY remaining tile?
+            // every 16 tiles (a batch boundary): does any user of the workgroup still have a chance in ANY remaining tile?
             const bool done = !(h == 0 && uvalid) || (S.cnt == N && pn * a.tile_norm_sufmax[t + 1] <= S.thr);
             if (!__syncthreads_or(!done)) break;
         } else {
@@ -493,24 +537,34 @@ inline void launch_scan_f32(const ScanArgs &a, hipStream_t stream, dim3 grid, si
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<K2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_topn_scan<K2>, grid, dim3(256), lds, stream, a);
 }
+template <int K16, int T, int WAVES>
+inline void launch_scan_bf16(const ScanArgs &a, hipStream_t stream) {
+    const size_t lds = scan_bf16_lds_bytes(a.k, a.N, T, WAVES);
+    const dim3 grid((unsigned)((a.nu + WAVES * 32 - 1) / (WAVES * 32)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan_bf16<K16, T, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_topn_scan_bf16<K16, T, WAVES>), grid, dim3(64 * WAVES), lds, stream, a);
+}
 template <int K16>
-inline void launch_scan_bf16(const ScanArgs &a, hipStream_t stream, dim3 grid, size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan_bf16<K16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_topn_scan_bf16<K16>, grid, dim3(256), lds, stream, a);
+inline void launch_scan_bf16_cfg(const ScanArgs &a, hipStream_t stream, int batch) {
+    // batch: tiles per re-score batch (0 = default).  The ring of batch + 1 fp32 tiles and the N slots of the workgroup's
+    // users must fit the CU's 160 KB: 8 waves of 32 users share one ring when batching.
+    if (batch == 0) batch = 4;
+    if (batch >= 4 && scan_bf16_lds_bytes(a.k, a.N, 4, 8) <= 160u * 1024u) launch_scan_bf16<K16, 4, 8>(a, stream);
+    else if (batch >= 2 && scan_bf16_lds_bytes(a.k, a.N, 2, 8) <= 160u * 1024u) launch_scan_bf16<K16, 2, 8>(a, stream);
+    else launch_scan_bf16<K16, 1, 4>(a, stream);
 }
 
 // force_f32 != 0: always the exact-f32-MFMA kernel.  Otherwise k in {16,32,64,128} takes the bf16
 // pre-filter kernel (identical results), anything else the f32 kernel.  Returns 1 if bf16 was used.
-inline int launch_scan(const ScanArgs &a, hipStream_t stream, int force_f32) {
+inline int launch_scan(const ScanArgs &a, hipStream_t stream, int force_f32, int batch = 0) {
     if (a.k > 256 || a.N > 100) return -1;
     const dim3 grid((unsigned)((a.nu + kScanWaves * 32 - 1) / (kScanWaves * 32)));
     if (!force_f32 && (a.k == 16 || a.k == 32 || a.k == 64 || a.k == 128)) {
-        const size_t lds = scan_bf16_lds_bytes(a.k, a.N);
         switch (a.k) {
-            case 16: launch_scan_bf16<1>(a, stream, grid, lds); break;
-            case 32: launch_scan_bf16<2>(a, stream, grid, lds); break;
-            case 64: launch_scan_bf16<4>(a, stream, grid, lds); break;
-            default: launch_scan_bf16<8>(a, stream, grid, lds); break;
+            case 16: launch_scan_bf16_cfg<1>(a, stream, batch); break;
+            case 32: launch_scan_bf16_cfg<2>(a, stream, batch); break;
+            case 64: launch_scan_bf16_cfg<4>(a, stream, batch); break;
+            default: launch_scan_bf16_cfg<8>(a, stream, batch); break;
         }
         return 1;
     }
