@@ -159,6 +159,7 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
 
 /* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
+ *   "scan_batch" bf16 scoring kernel: 0 (default) two item tiles per loop iteration and 256 users per workgroup, 1 one tile and 128 users
  *   "round_tpw" events per wave in the training round kernel: 0 = default (16 for k <= 64, 8 for k <= 128, else 4), 2, 4, 8, 16 (k <= 64 only)
  *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in staging rows,
  *               summed in ticket / event order when the row is rewritten; 2..4: that bound chosen explicitly (epoch

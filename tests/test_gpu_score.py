@@ -86,6 +86,11 @@ def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
     ms, events, rescored, used_bf16 = dev.scan_stats()
     assert ms > 0 and events >= len(users) * N
     assert used_bf16 == (k in (16, 32, 64, 128)) and (not used_bf16 or rescored >= events)
+    # both bf16 pre-filter kernels (two tiles per iteration / one) give the same lists and scores
+    dev.set_option('scan_batch', 1)
+    ids1, sc1 = dev.topn_scan(users, N, mp, mi)
+    dev.set_option('scan_batch', 0)
+    assert np.array_equal(ids1, ids) and np.array_equal(sc1, sc)
     # the exact f32-MFMA kernel and the bf16 pre-filter path give the same lists and scores
     dev.set_option('scan_f32', 1)
     ids2, sc2 = dev.topn_scan(users, N, mp, mi)
@@ -156,6 +161,10 @@ def test_full_size_scan_properties(dev, orc):
     dev.set_factors(P, Q)
     mp, mi = mask_rows(indptr, indices.reshape(-1).astype(np.int32), users)
     ids, sc = dev.topn_scan(users, N, mp, mi)
+    dev.set_option('scan_batch', 1)
+    ids1, sc1 = dev.topn_scan(users, N, mp, mi)
+    dev.set_option('scan_batch', 0)
+    assert np.array_equal(ids1, ids) and np.array_equal(sc1, sc)
     # slot 0 is the global maximum over candidates; scores are non-increasing; no masked item listed
     assert (np.diff(sc, axis=1) <= 0).all()
     for t in range(0, len(users), 37):

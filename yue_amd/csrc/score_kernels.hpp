@@ -532,6 +532,223 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
     if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
 }
 
+// Variant with TP tiles per loop iteration (one barrier per TP tiles): the MFMA chains of the iteration's tiles are
+// independent, so the pre-filter arithmetic of one tile runs while the matrix pipe works on the next; survivors of the TP
+// tiles are re-scored together at the end of the iteration.  LDS: two stages of TP tiles, fp32 and bf16 copies.
+__host__ __device__ inline size_t scan_bf16p_lds_bytes(int k, int N, int TP, int waves) {
+    const size_t tile = (size_t)(2 * TP) * kScanTile * ((k + 4) * sizeof(float) + (k + kScanBfPad) * 2u);
+    const size_t state = (size_t)waves * 32 * scan_ns(N) * (sizeof(float) + sizeof(int32_t));
+    return tile + state;
+}
+
+template <int K16, int TP, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf16p(ScanArgs a) {
+    static_assert(TP == 2, "survivor word: 64 bits");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int K = 16 * K16, LD = K + 4, LDB = K + kScanBfPad, NT = 64 * WAVES;
+    const int N = a.N, NS = scan_ns(N);
+    float *tile = reinterpret_cast<float *>(lds_raw);                                // [2][TP][32][LD] fp32
+    __bf16 *btile = reinterpret_cast<__bf16 *>(tile + 2 * TP * kScanTile * LD);      // [2][TP][32][LDB] bf16
+    float *st_a_all = reinterpret_cast<float *>(btile + 2 * TP * kScanTile * LDB);
+    int32_t *st_id_all = reinterpret_cast<int32_t *>(st_a_all + WAVES * 32 * NS);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t upos = (int64_t)blockIdx.x * (WAVES * 32) + w * 32 + r;
+    const bool uvalid = upos < a.nu;
+    const int32_t uid = a.users[uvalid ? upos : 0];
+    const float *prow = a.P + (int64_t)uid * K;
+
+    constexpr int KH = K / 2;
+    float mu;
+    float pf[KH];
+#pragma unroll
+    for (int e = 0; e < KH; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4 *>(prow + h * KH + e); pf[e] = v[0]; pf[e + 1] = v[1]; pf[e + 2] = v[2]; pf[e + 3] = v[3]; }
+    bf16x8 af[K16];
+#pragma unroll
+    for (int s = 0; s < K16; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) af[s][jj] = (__bf16)prow[16 * s + 8 * h + jj];
+    {
+        float ss = 0.0f;
+#pragma unroll
+        for (int e = 0; e < KH; ++e) ss = __builtin_fmaf(pf[e], pf[e], ss);
+        ss = lo_bcast(ss) + hi_bcast(ss);                      // sum of the two halves on both lanes
+        mu = __builtin_sqrtf(ss) * (1.01f / 128.0f);
+    }
+    const float pn = mu * (128.0f * 1.0001f / 1.01f);
+
+    // one stage = TP consecutive tiles = TP * 32 rows of Q, contiguous in memory
+    constexpr int ROWS = TP * kScanTile;
+    constexpr int PF4 = (ROWS * K / 4 + NT - 1) / NT;
+    int lds_off[PF4], ldb_off[PF4];
+#pragma unroll
+    for (int q = 0; q < PF4; ++q) {
+        const int el = (tid + NT * q) * 4; const int row = el / K;
+        lds_off[q] = row * LD + (el - row * K); ldb_off[q] = row * LDB + (el - row * K);
+    }
+    f32x4 pre[PF4];
+    float nu_next[TP];
+    const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
+    auto fetch = [&](int64_t it0) {
+        const int64_t limit = (a.n - it0) * K;
+        const float *src = a.Q + it0 * K;
+#pragma unroll
+        for (int q = 0; q < PF4; ++q) {
+            const int el = (tid + NT * q) * 4;
+            pre[q] = (el < ROWS * K && el < limit) ? *reinterpret_cast<const f32x4 *>(src + el) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < TP; ++q) { const int64_t tl = it0 / kScanTile + q; nu_next[q] = tl < ntiles ? a.tile_norm_max[tl] : 0.0f; }
+    };
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    auto commit = [&](int stage) {
+        float *dst = tile + stage * ROWS * LD;
+        __bf16 *bdst = btile + stage * ROWS * LDB;
+#pragma unroll
+        for (int q = 0; q < PF4; ++q)
+            if ((tid + NT * q) * 4 < ROWS * K) {
+                *reinterpret_cast<f32x4 *>(dst + lds_off[q]) = pre[q];
+                bf16x4 b;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) b[jj] = (__bf16)pre[q][jj];
+                *reinterpret_cast<bf16x4 *>(bdst + ldb_off[q]) = b;
+            }
+    };
+
+    ScanState S;
+    S.st_a = st_a_all + (w * 32 + r) * NS; S.st_id = st_id_all + (w * 32 + r) * NS;
+    S.cnt = 0; S.thr = -INFINITY; S.events = 0;
+    S.g_sc = a.out_scores + (uvalid ? upos : 0) * N;
+    S.g_id = a.out_ids + (uvalid ? upos : 0) * N;
+    int rescored = 0;
+    unsigned tiles_done = 0;
+    float thr_lane = -INFINITY;
+    int64_t mcur = 0, mend = 0;
+    int32_t mnext = 0x7fffffff;
+    if (h == 0 && uvalid) {
+        const int64_t mrow = a.mask_by_user ? (int64_t)uid : upos;
+        mcur = a.mask_ptr[mrow]; mend = a.mask_ptr[mrow + 1];
+        if (mcur < mend) mnext = a.mask_idx[mcur];
+    }
+
+    const int64_t niter = (ntiles + TP - 1) / TP;
+    fetch(0);
+    commit(0);
+    float nu[TP];
+#pragma unroll
+    for (int q = 0; q < TP; ++q) nu[q] = nu_next[q];
+    __syncthreads();
+
+    for (int64_t it = 0; it < niter; ++it) {
+        const int stage = (int)(it & 1);
+        const int64_t it0 = it * ROWS;                                 // first item of the iteration
+        const float *tb = tile + stage * ROWS * LD;
+        const __bf16 *tbb = btile + stage * ROWS * LDB;
+        if (it + 1 < niter) fetch(it0 + ROWS);
+        float numax = nu[0];
+#pragma unroll
+        for (int q = 1; q < TP; ++q) numax = fmaxf(numax, nu[q]);
+        const bool settled = !(h == 0 && uvalid) || (S.cnt == N && pn * numax <= S.thr);
+        unsigned long long cand = 0ull;
+        if (__ballot(!settled) != 0ull) {
+            tiles_done += (unsigned)min((int64_t)TP, ntiles - it * TP);
+            f32x16 acc[TP];
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+#pragma unroll
+                for (int z = 0; z < 16; ++z) acc[q][z] = 0.0f;
+                const __bf16 *irow = tbb + (q * kScanTile + r) * LDB + 8 * h;
+#pragma unroll
+                for (int s = 0; s < K16; ++s) {
+                    const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[s], acc[q], 0, 0, 0);
+                }
+            }
+            uint32_t pm[TP];
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+                // bar < score  <=>  (bar - score) carries the sign bit (a difference of two different floats is never +0):
+                // the 16 sign bits are shifted into one word (v_sub + v_alignbit per score, no condition codes), bit z = acc[z],
+                // then the four nibbles (rows 8g .. 8g+3 of the 32x32 block, + 4h) are spread to the item columns
+                const float bar = thr_lane - mu * nu[q];
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int z = 15; z >= 0; --z) bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(uint32_t, bar - acc[q][z]), 31);
+                const uint32_t pmask = (bits & 0xFu) | ((bits & 0xF0u) << 4) | ((bits & 0xF00u) << 8) | ((bits & 0xF000u) << 12);
+                pm[q] = pmask << (4 * h);
+            }
+            {   // both lanes of a user get all 64 columns: one swap per 32-bit word
+                uint32_t l0, h0, l1, h1;
+                half_bcast(pm[0], l0, h0); half_bcast(pm[1], l1, h1);
+                pm[0] = l0 | h0; pm[1] = l1 | h1;
+            }
+            const int64_t left = a.n - it0;
+            unsigned long long pm64 = (unsigned long long)pm[0] | ((unsigned long long)pm[1] << 32);
+            if (left < ROWS) pm64 &= (1ull << (unsigned)left) - 1ull;
+            if (h == 0 && uvalid) {
+                unsigned long long mb = 0ull;
+                while (mnext < it0 + ROWS) {
+                    if (mnext >= it0) mb |= 1ull << (unsigned)(mnext - it0);      // masked items of skipped iterations just pass by
+                    ++mcur;
+                    mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
+                }
+                cand = pm64 & ~mb;
+            }
+            // survivors of the iteration: the two-lane re-score pipeline of k_topn_scan_bf16
+            int c_prev = -1;
+            float s_prev = 0.0f;
+            for (;;) {
+                const int c_pop = (h == 0 && cand) ? __ffsll((long long)cand) - 1 : -1;
+                const int c_from = (int)lo_bcast((uint32_t)c_prev);
+                const float s_from = lo_bcast(s_prev);
+                const int c_cur = h ? c_from : c_pop;
+                float sc = h ? s_from : 0.0f;
+                if (__ballot(c_cur >= 0) == 0ull) break;
+                if (c_pop >= 0) cand &= cand - 1;
+                if (c_cur >= 0) {
+                    const float *qrow = tb + c_cur * LD + h * KH;
+#pragma unroll
+                    for (int e = 0; e < KH; e += 4) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4 *>(qrow + e);
+                        sc = __builtin_fmaf(pf[e], qv[0], sc); sc = __builtin_fmaf(pf[e + 1], qv[1], sc);
+                        sc = __builtin_fmaf(pf[e + 2], qv[2], sc); sc = __builtin_fmaf(pf[e + 3], qv[3], sc);
+                    }
+                }
+                const float s_done = hi_bcast(sc);
+                const int c_done = (int)hi_bcast((uint32_t)c_cur);
+                if (h == 0 && c_done >= 0) {
+                    ++rescored;
+                    if (!(S.cnt == N && !(S.thr < s_done))) scan_push(S, N, s_done, (int32_t)(it0 + c_done), a.true_topn);
+                }
+                c_prev = c_cur;
+                s_prev = sc;
+            }
+            thr_lane = lo_bcast(S.thr);
+        }
+        if (it + 1 < niter) commit(stage ^ 1);
+#pragma unroll
+        for (int q = 0; q < TP; ++q) nu[q] = nu_next[q];
+        if ((it & 7) == 7 && it + 1 < niter) {
+            const bool done = !(h == 0 && uvalid) || (S.cnt == N && pn * a.tile_norm_sufmax[(it + 1) * TP] <= S.thr);
+            if (!__syncthreads_or(!done)) break;
+        } else {
+            __syncthreads();
+        }
+    }
+
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
+    if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
+}
+
+template <int K16, int TP, int WAVES>
+inline void launch_scan_bf16p(const ScanArgs &a, hipStream_t stream) {
+    const size_t lds = scan_bf16p_lds_bytes(a.k, a.N, TP, WAVES);
+    const dim3 grid((unsigned)((a.nu + WAVES * 32 - 1) / (WAVES * 32)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan_bf16p<K16, TP, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_topn_scan_bf16p<K16, TP, WAVES>), grid, dim3(64 * WAVES), lds, stream, a);
+}
+
 template <int K2>
 inline void launch_scan_f32(const ScanArgs &a, hipStream_t stream, dim3 grid, size_t lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topn_scan<K2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -546,11 +763,11 @@ inline void launch_scan_bf16(const ScanArgs &a, hipStream_t stream) {
 }
 template <int K16>
 inline void launch_scan_bf16_cfg(const ScanArgs &a, hipStream_t stream, int batch) {
-    // batch: tiles per re-score batch (0 = default).  The ring of batch + 1 fp32 tiles and the N slots of the workgroup's
-    // users must fit the CU's 160 KB: 8 waves of 32 users share one ring when batching.
-    if (batch == 0) batch = 4;
-    if (batch >= 4 && scan_bf16_lds_bytes(a.k, a.N, 4, 8) <= 160u * 1024u) launch_scan_bf16<K16, 4, 8>(a, stream);
-    else if (batch >= 2 && scan_bf16_lds_bytes(a.k, a.N, 2, 8) <= 160u * 1024u) launch_scan_bf16<K16, 2, 8>(a, stream);
+    // batch 0 (default): k_topn_scan_bf16p, two tiles per iteration, 8 waves of 32 users per workgroup -- if the N slots
+    // of 256 users fit beside the tiles in the CU's 160 KB; batch 1 (and the fallback): k_topn_scan_bf16 with one tile
+    // per iteration and 4 waves per workgroup.  (Measured on C5, 1M users, random factors: 251 ms against 325 ms; batches
+    // of 2 / 4 tiles in the one-tile kernel 288 / 267 ms -- profiles/README.md.)
+    if (batch != 1 && scan_bf16p_lds_bytes(a.k, a.N, 2, 8) <= 160u * 1024u) launch_scan_bf16p<K16, 2, 8>(a, stream);
     else launch_scan_bf16<K16, 1, 4>(a, stream);
 }
 

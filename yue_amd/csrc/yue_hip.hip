@@ -97,7 +97,7 @@ struct yue_ctx {
     int scan_used_bf16 = 0;
     // options (yue_set_option)
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
-    int opt_scan_batch = 0;              // bf16 scoring kernel: tiles per re-score batch (0 = default 4; 1, 2, 4)
+    int opt_scan_batch = 0;              // bf16 scoring kernel: 0 = two tiles per iteration, 256 users per workgroup (default); 1 = one tile, 128 users
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 2..4: rows with up to that many touches are staged (epoch path)
@@ -922,7 +922,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail(YUE_ERR_ARG, "yue_set_option: null argument");
     const std::string key(name);
     if (key == "scan_f32") { c->opt_scan_f32 = value != 0; return YUE_OK; }
-    if (key == "scan_batch") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(YUE_ERR_ARG, "yue_set_option: scan_batch must be 0, 1, 2 or 4"); c->opt_scan_batch = (int)value; return YUE_OK; }
+    if (key == "scan_batch") { if (value != 0 && value != 1) return fail(YUE_ERR_ARG, "yue_set_option: scan_batch must be 0 or 1"); c->opt_scan_batch = (int)value; return YUE_OK; }
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "round_stage") {
         if (value < 0 || value > (int64_t)yue::kMetaStageMax) return fail(YUE_ERR_ARG, "yue_set_option: round_stage must be 0, 1 or 2..4");
