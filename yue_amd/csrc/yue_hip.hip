@@ -289,7 +289,8 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
     int per_cu = 0, cus = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_meta, 1024, lds));
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    const int64_t grid = std::min<int64_t>(R * ma.G, (int64_t)std::max(per_cu, 1) * cus);
+    // a multiple of 8 workgroups (k_round_meta deals the work out per XCD), at most one resident set
+    const int64_t grid = std::max<int64_t>(8, std::min<int64_t>((R * ma.G + 7) / 8 * 8, (int64_t)std::max(per_cu, 1) * cus / 8 * 8));
     hipLaunchKernelGGL(yue::k_round_meta, dim3((unsigned)grid), dim3(1024), lds, c->stream, ma);
     HIPCHK(hipGetLastError());
     return YUE_OK;
