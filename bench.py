@@ -99,6 +99,12 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
             'hogwild': {'value': Sh / dth, 'cores': threads, 'sample': 'first %d triplets, the C loop raced by %d threads over slices of the stream (result depends on the interleaving), %.1f s' % (Sh, threads, dth)}}
 
 
+def scan_kernel_label(dev, k):
+    if dev.get_option('scan_batch') == 1:
+        return 'k_topn_scan_bf16<K16=%d, 1 tile per iteration, 4 waves>' % (k // 16)
+    return 'k_topn_scan_bf16p<K16=%d, 2 tiles per iteration, 8 waves>' % (k // 16)
+
+
 def round_kernel_label(dev, k):
     kr = 1 if k <= 64 else 2 if k <= 128 else 4
     if dev.get_option('round_path') == 1:
@@ -178,7 +184,7 @@ def secondary_scoring(dev, data, m, n, k, no_cpu):
                                    'host copies of ids/scores included in value' % (nu, m, n, k, N),
                        'state_machine_events_per_user': events / nu, 'exact_rescores_per_user': rescored / nu,
                        'tiles_scored_fraction': done / max(1, total)},
-            'roofline': {'bound': 'mfma', 'kernel': ('k_topn_scan_bf16<K16=%d>' % (k // 16)) if used_bf16 else 'k_topn_scan (f32 MFMA)', 'achieved': ach / 1e12,
+            'roofline': {'bound': 'mfma', 'kernel': scan_kernel_label(dev, k) if used_bf16 else 'k_topn_scan (f32 MFMA)', 'achieved': ach / 1e12,
                          'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel_ms_per_scan': kms / steps, 'traffic': None},
             'cpu_baseline': None if no_cpu else scoring_cpu_baseline(dev, data, users, ids, N, n, 4.0)}
 
@@ -224,7 +230,7 @@ def bench_scoring(args, cp):
             'config': {'workload': '%s: %d users x %d items, k=%d, N=%d, training items masked, host copies of ids/scores included in value'
                                    % (args.workload.upper(), m, n, k, N), 'state_machine_events_per_user': events / max(1, len(users)),
                        'exact_rescores_per_user': rescored / max(1, len(users)), 'bf16_prefilter': used_bf16, 'tiles_scored_fraction': done / max(1, total)},
-            'roofline': {'bound': 'mfma', 'kernel': ('k_topn_scan_bf16<K16=%d>' % (k // 16)) if used_bf16 else ('k_topn_scan<K2=%d>' % (k // 2)), 'achieved': ach / 1e12, 'peak': peak / 1e12,
+            'roofline': {'bound': 'mfma', 'kernel': scan_kernel_label(dev, k) if used_bf16 else ('k_topn_scan<K2=%d>' % (k // 2)), 'achieved': ach / 1e12, 'peak': peak / 1e12,
                          'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel_ms_per_scan': kms / args.steps, 'traffic': None},
             'cpu_baseline': cpu}))
     dev.close()
