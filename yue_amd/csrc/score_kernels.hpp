@@ -645,7 +645,11 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
         const int64_t it0 = it * ROWS;                                 // first item of the iteration
         const float *tb = tile + stage * ROWS * LD;
         const __bf16 *tbb = btile + stage * ROWS * LDB;
+#if defined(YUE_SCAN_ABL) && (YUE_SCAN_ABL & 2)     // timing-only ablation: no global loads of item tiles after the first
+        (void)0;
+#else
         if (it + 1 < niter) fetch(it0 + ROWS);
+#endif
         float numax = nu[0];
 #pragma unroll
         for (int q = 1; q < TP; ++q) numax = fmaxf(numax, nu[q]);
@@ -655,9 +659,11 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
             tiles_done += (unsigned)min((int64_t)TP, ntiles - it * TP);
             f32x16 acc[TP];
 #pragma unroll
-            for (int q = 0; q < TP; ++q) {
+            for (int q = 0; q < TP; ++q)
 #pragma unroll
                 for (int z = 0; z < 16; ++z) acc[q][z] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
                 const __bf16 *irow = tbb + (q * kScanTile + r) * LDB + 8 * h;
 #pragma unroll
                 for (int s = 0; s < K16; ++s) {
@@ -693,7 +699,11 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
                     ++mcur;
                     mnext = mcur < mend ? a.mask_idx[mcur] : 0x7fffffff;
                 }
+#if defined(YUE_SCAN_ABL) && (YUE_SCAN_ABL & 1)     // timing-only ablation: no survivors after the seeds
+                cand = S.cnt < N ? (pm64 & ~mb) : 0ull;
+#else
                 cand = pm64 & ~mb;
+#endif
             }
             // survivors of the iteration: the two-lane re-score pipeline of k_topn_scan_bf16
             int c_prev = -1;
@@ -733,7 +743,11 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
             const bool done = !(h == 0 && uvalid) || (S.cnt == N && pn * a.tile_norm_sufmax[(it + 1) * TP] <= S.thr);
             if (!__syncthreads_or(!done)) break;
         } else {
+#if defined(YUE_SCAN_ABL) && (YUE_SCAN_ABL & 4)     // timing-only ablation: no barrier between the iterations
+            __builtin_amdgcn_wave_barrier();
+#else
             __syncthreads();
+#endif
         }
     }
 
