@@ -290,9 +290,11 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
 // ------------------------------------------------------------------------------------------
 // bf16 pre-filter in front of the exact path (k = 16*K16 <= 128).
 // The 32x32 tile of scores comes from v_mfma_f32_32x32x16_bf16 on bf16-rounded factors (1/16 of the
-// f32-MFMA time).  |bf16 score - exact score| <= 2^-8 * sum|p_e q_e| <= 2^-8 ||P_u|| ||Q_i||, so a
-// pair can only matter to the state machine if  bf16 score + 2^-7 ||P_u|| ||Q_i|| > threshold_u
-// (margin doubled for slack).  Those few survivors are re-scored exactly -- the same k-ascending
+// f32-MFMA time).  Rounding a factor to bf16 (8 significant bits, to nearest) moves it by at most 2^-8 of
+// its size, a product of two rounded factors by at most (2^-7 + 2^-16) |p_e q_e|; the fp32 accumulation of the
+// MFMA and of the exact chain add a few 2^-17 sum|p_e q_e|.  Hence |bf16 score - exact score| <= 1.005 * 2^-7 *
+// sum|p_e q_e| <= 1.005 * 2^-7 ||P_u|| ||Q_i||, and a pair can only matter to the state machine if
+// bf16 score + 1.01 * 2^-7 ||P_u|| max||Q_tile|| > threshold_u.  Those few survivors are re-scored exactly -- the same k-ascending
 // fp32 fma chain as k_topn_scan / the oracle, P row in registers, Q row from the fp32 LDS tile --
 // and only the exact score enters the state machine: results are identical to the f32 kernel.
 // ------------------------------------------------------------------------------------------
