@@ -20,10 +20,10 @@ ap.add_argument('--users', type=int, default=1000000)
 ap.add_argument('--items', type=int, default=200000)
 ap.add_argument('--d', type=int, default=50)
 ap.add_argument('--k', type=int, default=128)
-ap.add_argument('--round', type=int, default=32768)
+ap.add_argument('--round', type=int, default=0, help='round size (0 = the library default)')
 ap.add_argument('--stage', type=int, default=1)
 ap.add_argument('--tpw', type=int, default=0)
-ap.add_argument('--launch', type=int, default=700)
+ap.add_argument('--launch', type=int, default=150, help='which round launch of the second epoch to stamp')
 args = ap.parse_args()
 
 _shim.LIB_PATH = os.path.join(ROOT, 'yue_amd', 'csrc', 'libyue_hip_stamps.so')
@@ -45,8 +45,8 @@ nw = C.c_int64()
 lib.yue_debug_get_stamps(dev._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(cap), C.byref(nw))
 st = buf[:nw.value].astype(np.float64) * 0.01               # 100 MHz -> microseconds
 t0 = st[:, 0].min()
-names = ['header (scalar loads)', 'row gathers', 'dots + sigmoids', 'issue of stores / atomics', 'drain own stores',
-         'count decrements', 'last-toucher rewrites']
+names = ['header (scalar loads)', 'row gathers', 'dots + sigmoids', 'issue of stores / atomics', 'drain own stores (k_round)',
+         'count decrements (k_round)', 'last-toucher rewrites (k_round) / drain of the stores (k_round_m)']
 print('waves %d   launch span (first start .. last end) %.1f us' % (nw.value, st[:, 7].max() - t0))
 print('wave start  : mean %.1f  p50 %.1f  p99 %.1f  max %.1f us after the first' % (
     (st[:, 0] - t0).mean(), np.percentile(st[:, 0] - t0, 50), np.percentile(st[:, 0] - t0, 99), (st[:, 0] - t0).max()))

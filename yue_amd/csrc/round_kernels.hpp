@@ -195,6 +195,11 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
     }
 }
 
+// TPW consecutive words of an event array, loaded as one block (4-byte alignment: scalar block loads need no more)
+constexpr int kHeaderSlack = 16;           // words of slack the event and metadata arrays carry behind their last event
+template <int TPW>
+struct __attribute__((aligned(4))) HeaderBlock { int32_t w[TPW]; };
+
 struct RoundMArgs {
     int64_t e_begin, e_end;      // events updated by this launch
     int staged;                  // 1: the staging rows are in use (the metadata was made with stage_max > 1)
@@ -215,15 +220,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
     if (base >= ra.e_end) return;
     YUE_STAMP(0, "");
 
-    // batch header through the scalar unit: (u, i, j) and the two metadata words of the TPW events
+    // batch header through the scalar unit: (u, i, j) and the two metadata words of the TPW events, ONE block load per array
+    // (the arrays carry kHeaderSlack words of slack behind their last event; with per-event clamped indices the compiler
+    // issued the 5 * TPW words as a chain of ten dependent groups of single-word loads: 5 us of a wave's 16)
     int hu[TPW], hi_[TPW], hj[TPW];
     uint32_t hmi[TPW], hmj[TPW];
+    {
+        const HeaderBlock<TPW> bu = *reinterpret_cast<const HeaderBlock<TPW> *>(evu + base);
+        const HeaderBlock<TPW> bi = *reinterpret_cast<const HeaderBlock<TPW> *>(evi + base);
+        const HeaderBlock<TPW> bj = *reinterpret_cast<const HeaderBlock<TPW> *>(evj + base);
+        const HeaderBlock<TPW> bmi = *reinterpret_cast<const HeaderBlock<TPW> *>(mti + base);
+        const HeaderBlock<TPW> bmj = *reinterpret_cast<const HeaderBlock<TPW> *>(mtj + base);
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const bool ex = base + t < ra.e_end;
-        const int64_t ix = ex ? base + t : ra.e_end - 1;
-        hu[t] = evu[ix]; hi_[t] = evi[ix]; hj[t] = ex ? evj[ix] : -1;
-        hmi[t] = ex ? mti[ix] : 0u; hmj[t] = ex ? mtj[ix] : 0u;
+        for (int t = 0; t < TPW; ++t) {
+            const bool ex = base + t < ra.e_end;
+            hu[t] = ex ? bu.w[t] : bu.w[0]; hi_[t] = ex ? bi.w[t] : bi.w[0]; hj[t] = ex ? bj.w[t] : -1;
+            hmi[t] = ex ? (uint32_t)bmi.w[t] : 0u; hmj[t] = ex ? (uint32_t)bmj.w[t] : 0u;
+        }
     }
     int j = -1;                                          // lane t keeps the negative of event t (the loss works per lane)
 #pragma unroll
@@ -328,7 +341,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    YUE_STAMP(4, "");
+    YUE_STAMP(4, ""); YUE_STAMP(5, ""); YUE_STAMP(6, "");      // (no retire phases in this kernel: the diagnostic tool's columns 5, 6 stay empty)
 #pragma unroll
     for (int off = 1; off < TPW; off <<= 1) nll += __shfl_xor(nll, off);
     if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave & (kNllSlots - 1)), nll);

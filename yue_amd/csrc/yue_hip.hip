@@ -268,7 +268,7 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
 int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int64_t> &bounds) {
     const int64_t R = (int64_t)bounds.size() - 1;
     const int64_t E = bounds.back();
-    HIPCHK(c->meta_i.resize((size_t)std::max<int64_t>(E, 1))); HIPCHK(c->meta_j.resize((size_t)std::max<int64_t>(E, 1)));
+    HIPCHK(c->meta_i.resize((size_t)E + yue::kHeaderSlack)); HIPCHK(c->meta_j.resize((size_t)E + yue::kHeaderSlack));   // (+ slack: k_round_m reads whole header blocks)
     HIPCHK(c->round_rows.resize((size_t)R)); HIPCHK(c->d_bounds.resize((size_t)R + 1));
     if (c->h_bounds != bounds) {                       // the same blocks epoch after epoch: uploaded once
         HIPCHK(hipStreamSynchronize(c->stream));       // an earlier upload may still read h_bounds
@@ -593,7 +593,7 @@ int yue_set_interactions(yue_ctx *c, const int64_t *indptr, const int32_t *indic
     c->E = E; c->nnz = nnz;
     c->h_ev_ptr.assign(ev_ptr, ev_ptr + m + 1);
     HIPCHK(c->indptr.resize(m + 1)); HIPCHK(c->indices.resize(std::max<int64_t>(nnz, 1)));
-    HIPCHK(c->ev_u.resize(std::max<int64_t>(E, 1))); HIPCHK(c->ev_i.resize(std::max<int64_t>(E, 1))); HIPCHK(c->ev_j.resize(std::max<int64_t>(E, 1)));
+    HIPCHK(c->ev_u.resize((size_t)E + yue::kHeaderSlack)); HIPCHK(c->ev_i.resize((size_t)E + yue::kHeaderSlack)); HIPCHK(c->ev_j.resize((size_t)E + yue::kHeaderSlack));   // (+ slack: k_round_m reads whole header blocks)
     HIPCHK(hipMemcpyAsync(c->indptr.p, indptr, (m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->ev_u.p, evu.data(), E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
