@@ -15,24 +15,10 @@
 #include "train_kernels.hpp"
 
 // timing-only ablations of diagnostic builds (results wrong by construction; never defined in the product build)
-#ifdef YUE_ABL_NO_STAGE
-#define YUE_M_STAGE(val, rs, vo, so) asm volatile("" :: "v"(val))
-#elif defined(YUE_EXP_STAGE_NT)
-#define YUE_M_STAGE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 2)
-#else
-#define YUE_M_STAGE(val, rs, vo, so) YUE_BSTORE(val, rs, vo, so)
-#endif
 #ifdef YUE_ABL_NO_HOT
 #define YUE_M_HOT(val, rs, vo, so) asm volatile("" :: "v"(val))
 #else
 #define YUE_M_HOT(val, rs, vo, so) YUE_BATOMIC(val, rs, vo, so)
-#endif
-#ifdef YUE_ABL_NO_INPLACE
-#define YUE_M_INPLACE(val, rs, vo, so) asm volatile("" :: "v"(val))
-#elif defined(YUE_EXP_INPLACE_NT)
-#define YUE_M_INPLACE(val, rs, vo, so) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (val)), (rs), (vo), (so), 2)
-#else
-#define YUE_M_INPLACE(val, rs, vo, so) YUE_BSTORE(val, rs, vo, so)
 #endif
 #ifdef YUE_ABL_NO_DP
 #define YUE_M_DP(val, rs, vo, so) asm volatile("" :: "v"(val))
@@ -256,12 +242,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
     const uint64_t qbytes = (uint64_t)a.n * row_bytes, pbytes = (uint64_t)(a.m - u0) * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
     const int prec = (int)(pbytes < 0x7fffffffull ? pbytes : 0x7fffffffull);
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(a.Q, 0, qrec, kRsrcFlags);
+    // the staging rows lie behind the n item rows in the same allocation (TrainArgs.stage == Q + n * k): one descriptor
+    // serves gathers, in-place stores and staged stores -- a store's destination is a scalar offset, not a branch
+    const unsigned stage0 = (unsigned)a.n * row_bytes;
+    const uint64_t qsbytes = qbytes + (ra.staged ? 2ull * (uint64_t)(ra.e_end - ra.e_begin) * row_bytes : 0ull);
+    const int qsrec = (int)(qsbytes < 0x7fffffffull ? qsbytes : 0x7fffffffull);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(a.Q, 0, qsrec, kRsrcFlags);
     const auto rsdQ = __builtin_amdgcn_make_buffer_rsrc(a.dQ, 0, qrec, kRsrcFlags);
     const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.P + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
     const auto rsdP = __builtin_amdgcn_make_buffer_rsrc(a.dP + (uint64_t)u0 * k, 0, prec, kRsrcFlags);
-    // staging rows of this round: at most 2 per event (the host keeps 2 * events * row_bytes below 2^31 when staged)
-    const auto rsS = __builtin_amdgcn_make_buffer_rsrc(a.stage, 0, ra.staged ? (int)(2u * (unsigned)(ra.e_end - ra.e_begin) * row_bytes) : 0, kRsrcFlags);
 
     unsigned oi[TPW], oj[TPW], ou[TPW], ru_[TPW];
     bool ok[TPW];
@@ -310,21 +299,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
         const float c = rdlane(cs, t);
         const unsigned cli = meta_class(hmi[t]), clj = meta_class(hmj[t]);
         const bool uniq_i = cli == 1u, uniq_j = clj == 1u;
-        const bool stg_i = cli < kMetaHot, stg_j = clj < kMetaHot;         // (and not unique: tested second)
-        const unsigned si = (meta_payload(hmi[t]) + meta_ticket(hmi[t])) * row_bytes;   // my staging rows
-        const unsigned sj = (meta_payload(hmj[t]) + meta_ticket(hmj[t])) * row_bytes;
+        const bool hot_i = cli >= kMetaHot, hot_j = clj >= kMetaHot;
+        // where the row's store goes: the row itself (only touch of the round) or the touch's staging row (block + ticket)
+        const unsigned wi = uniq_i ? oi[t] : stage0 + (meta_payload(hmi[t]) + meta_ticket(hmi[t])) * row_bytes;
+        const unsigned wj = uniq_j ? oj[t] : stage0 + (meta_payload(hmj[t]) + meta_ticket(hmj[t])) * row_bytes;
         if (ok[t]) {                                     // wave-uniform
             run_ok = true;
+            Elem o[KR];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                const Elem o = bpr_elem(p[t][r], qi[t][r], qj[t][r], c, a.ru, a.ri);
-                if (uniq_i) YUE_M_INPLACE(o.qi2, rsQ, vo[r], oi[t]);
-                else if (stg_i) YUE_M_STAGE(o.qi2 - qi[t][r], rsS, vo[r], si);
-                else YUE_M_HOT(o.qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
-                if (uniq_j) YUE_M_INPLACE(o.qj2, rsQ, vo[r], oj[t]);
-                else if (stg_j) YUE_M_STAGE(o.qj2 - qj[t][r], rsS, vo[r], sj);
-                else YUE_M_HOT(o.qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
-                dp[r] += o.p2 - p[t][r];
+            for (int r = 0; r < KR; ++r) { o[r] = bpr_elem(p[t][r], qi[t][r], qj[t][r], c, a.ru, a.ri); dp[r] += o[r].p2 - p[t][r]; }
+            // the new row in place, or (new - old) to the staging row: one store, value and offset selected; a hot row's
+            // difference goes into dQ with float atomics (one wave-uniform branch per touch)
+            if (!hot_i) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_BSTORE(uniq_i ? o[r].qi2 : o[r].qi2 - qi[t][r], rsQ, vo[r], wi);
+            } else {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_M_HOT(o[r].qi2 - qi[t][r], rsdQ, vo[r], oi[t]);
+            }
+            if (!hot_j) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_BSTORE(uniq_j ? o[r].qj2 : o[r].qj2 - qj[t][r], rsQ, vo[r], wj);
+            } else {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_M_HOT(o[r].qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
             }
         }
         // end of a run of equal users (or of the batch): flush the summed P[u] differences
