@@ -308,8 +308,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Exchange between the two lanes (r, 0) / (r, 1) = lanes r and r + 32 of a user: v_permlane32_swap (gfx950) instead of a
 // ds_bpermute round trip through the LDS.  lo: every lane gets the value of lane (lane & 31); hi: of lane 32 + (lane & 31).
 __device__ __forceinline__ void half_bcast(uint32_t v, uint32_t &lo, uint32_t &hi) {
-    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    lo = sw[0]; hi = sw[1];
+    // (inline assembly: see wave_sum in train_kernels.hpp about the builtin)
+    lo = v; hi = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
 }
 __device__ __forceinline__ uint32_t lo_bcast(uint32_t v) { uint32_t lo, hi; half_bcast(v, lo, hi); return lo; }
 __device__ __forceinline__ uint32_t hi_bcast(uint32_t v) { uint32_t lo, hi; half_bcast(v, lo, hi); return hi; }

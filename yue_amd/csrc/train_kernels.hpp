@@ -105,14 +105,21 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // Sum over the 64 lanes in the canonical order of oracle/bpr_oracle.c:dot64 -- butterfly with
 // partner lane^1, ^2, ^4, ^8, ^16, then (lanes 0-31) + (lanes 32-63).  The first four steps are
 // DPP-fused adds (quad_perm, quad_perm, row_half_mirror, row_mirror: same operands as the xor
-// partners because the value is already constant over the smaller groups), xor 16 is a ds_swizzle.
+// partners because the value is already constant over the smaller groups), xor 16 is a v_permlane16_swap of the value with itself.
 // Returns the total as a wave-uniform value.
 __device__ __forceinline__ float wave_sum(float v) {
     v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
     v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
     v = v + dpp_mov<0x141>(v);      // row_half_mirror
     v = v + dpp_mov<0x140>(v);      // row_mirror
-    v = v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // swap 16
+    // partner lane ^ 16: v_permlane16_swap (gfx950) of the value with itself leaves rows 0, 0, 2, 2 in one result and rows
+    // 1, 1, 3, 3 in the other -- their sum is v + v(lane ^ 16) on every lane (the add commutes), without the LDS round
+    // trip of a ds_swizzle (16 of them sat in the latency chain of every round-kernel wave)
+    // (written as inline assembly: through __builtin_amdgcn_permlane16_swap this compiler adds the FIRST result to itself;
+    // the s_nops cover the VALU-write -> lane-crossing-read wait states the compiler would otherwise count for us)
+    float w = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v), "+v"(w));
+    v = v + w;
     return rdlane(v, 0) + rdlane(v, 32);
 }
 
