@@ -271,6 +271,29 @@ def test_default_round_size_is_one_resident_wave_set(orc):
     assert rel_err(out[0][1], Po) < TOL and rel_err(out[0][2], Qo) < TOL and abs(out[0][0] - nll_o) <= 1e-9 * abs(nll_o)
 
 
+def test_default_round_size_grows_with_the_item_count():
+    # epoch path: up to 3 resident sets of the update kernel, as long as a round holds at most one event per item row
+    from yue_amd._shim import Device
+    k = 128
+    sizes = {}
+    for n in (1000, 130000, 200000, 400000):
+        dev = Device(0, raise_errors=True)
+        dev.set_factors(np.zeros((8, k), np.float32), np.zeros((n, k), np.float32))
+        sizes[n] = dev.default_round_events()
+        assert dev.get_option('round_path') == 1
+        dev.set_option('round_meta', 0)                      # the kernel that finishes contended rows inside the launch: one set of its own
+        one_old = dev.default_round_events()
+        assert dev.get_option('round_path') == 0 and one_old % 1024 == 0 and one_old <= sizes[1000]
+        dev.close()
+    one = sizes[1000]
+    assert one % 1024 == 0
+    assert sizes[130000] == one * min(3, 130000 // one) and sizes[200000] == one * min(3, 200000 // one) and sizes[400000] == 3 * one
+    dev = Device(0, raise_errors=True)                           # item shards beyond the pre-pass's range budget stay on k_round
+    dev.set_factors(np.zeros((8, 16), np.float32), np.zeros((500000, 16), np.float32))
+    assert dev.get_option('round_path') == 0
+    dev.close()
+
+
 def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):
     # user 0 listened to all but one item (sampler mostly rejects), user 1 has no events at all
     m, n, k = 3, 40, 16
