@@ -593,16 +593,24 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
     f32x4 pre[PF4];
     float nu_next[TP];
     const int64_t ntiles = (a.n + kScanTile - 1) / kScanTile;
+    constexpr bool kWhole = (ROWS * K / 4) % NT == 0;          // every thread moves whole float4s of a stage (K >= 32)
     auto fetch = [&](int64_t it0) {
-        const int64_t limit = (a.n - it0) * K;
         const float *src = a.Q + it0 * K;
+        if (kWhole && it0 + ROWS <= a.n) {                     // a whole stage: no per-element bounds (all but the last iteration)
 #pragma unroll
-        for (int q = 0; q < PF4; ++q) {
-            const int el = (tid + NT * q) * 4;
-            pre[q] = (el < ROWS * K && el < limit) ? *reinterpret_cast<const f32x4 *>(src + el) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < PF4; ++q) pre[q] = *reinterpret_cast<const f32x4 *>(src + (tid + NT * q) * 4);
+#pragma unroll
+            for (int q = 0; q < TP; ++q) nu_next[q] = a.tile_norm_max[it0 / kScanTile + q];
+        } else {
+            const int64_t limit = (a.n - it0) * K;
+#pragma unroll
+            for (int q = 0; q < PF4; ++q) {
+                const int el = (tid + NT * q) * 4;
+                pre[q] = (el < ROWS * K && el < limit) ? *reinterpret_cast<const f32x4 *>(src + el) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < TP; ++q) { const int64_t tl = it0 / kScanTile + q; nu_next[q] = tl < ntiles ? a.tile_norm_max[tl] : 0.0f; }
         }
-#pragma unroll
-        for (int q = 0; q < TP; ++q) { const int64_t tl = it0 / kScanTile + q; nu_next[q] = tl < ntiles ? a.tile_norm_max[tl] : 0.0f; }
     };
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     auto commit = [&](int stage) {
@@ -610,7 +618,7 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
         __bf16 *bdst = btile + stage * ROWS * LDB;
 #pragma unroll
         for (int q = 0; q < PF4; ++q)
-            if ((tid + NT * q) * 4 < ROWS * K) {
+            if (kWhole || (tid + NT * q) * 4 < ROWS * K) {
                 *reinterpret_cast<f32x4 *>(dst + lds_off[q]) = pre[q];
                 bf16x4 b;
 #pragma unroll
@@ -708,9 +716,11 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
                 cand = pm64 & ~mb;
 #endif
             }
-            // survivors of the iteration: the two-lane re-score pipeline of k_topn_scan_bf16
+            // survivors of the iteration: the two-lane re-score pipeline of k_topn_scan_bf16 (not entered when no user of
+            // the wave has one: the common case on trained factors)
             int c_prev = -1;
             float s_prev = 0.0f;
+            if (__ballot(cand != 0ull) != 0ull) {
             for (;;) {
                 const int c_pop = (h == 0 && cand) ? __ffsll((long long)cand) - 1 : -1;
                 const int c_from = (int)lo_bcast((uint32_t)c_prev);
@@ -738,6 +748,7 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
                 s_prev = sc;
             }
             thr_lane = lo_bcast(S.thr);
+            }
         }
         if (it + 1 < niter) commit(stage ^ 1);
 #pragma unroll
