@@ -49,3 +49,40 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(import|from)\s+oracle\b', src, re.M), f
                 assert 'liboracle' not in src, f
+
+
+def test_round_kernels_fit_the_residency_the_host_assumes(tmp_path):
+    """default_round_events (csrc/yue_hip.hip) sizes a round for 7 resident workgroups per CU of k_round_m and 6 of k_round:
+    that holds while the kernels stay within 96 / 112 allocated SGPRs and 72 / 80 VGPRs without scratch (MI355X residency
+    rule: floor(800 / (SGPRs rounded up to 16 + 16)) workgroups of 4 waves, 512 VGPRs per SIMD).  Compiles the device code
+    once more with the compiler's resource remarks (about a minute)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src = os.path.join(ROOT, 'yue_amd', 'csrc', 'yue_hip.hip')
+    out = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S', '--cuda-device-only',
+                          '-Rpass-analysis=kernel-resource-usage', '-o', str(tmp_path / 'yue_hip.s'), src],
+                         capture_output=True, text=True, cwd=os.path.dirname(src))
+    assert out.returncode == 0, out.stderr[-2000:]
+    usage = {}
+    name = None
+    for line in out.stderr.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r'remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]): (\d+)', line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    # the instantiations the default events-per-wave choice launches: k <= 64 -> <1,16>, k <= 128 -> <2,8>, else <4,4>
+    seen = 0
+    for fn, u in usage.items():
+        for kr, tpw in ((1, 16), (2, 8), (4, 4)):
+            if 'k_round_mILi%dELi%dEE' % (kr, tpw) in fn:
+                assert u['TotalSGPRs'] <= 96 and u['VGPRs'] <= 72 and u['ScratchSize [bytes/lane]'] == 0, (fn, u)
+                seen += 1
+            if '7k_roundILi%dELi%dEE' % (kr, tpw) in fn:
+                assert u['TotalSGPRs'] <= 112 and u['VGPRs'] <= 80 + 8 * (kr == 4) and u['ScratchSize [bytes/lane]'] == 0, (fn, u)
+                seen += 1
+    assert seen == 6, sorted(usage)
