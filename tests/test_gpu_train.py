@@ -391,6 +391,48 @@ def test_full_size_properties(dev):
     assert rel_err(P2, P) < TOL and rel_err(Q2, Q) < TOL
 
 
+@pytest.mark.parametrize('case,k,W', [(0, 200, 1), (1, 256, 37), (2, 192, 5), (3, 100, 100000), (4, 33, 100000), (5, 100, 1), (6, 7, 1),
+                                      (7, 33, 37), (8, 128, 4096), (9, 7, 256), (10, 3, 4096), (11, 64, 1000), (12, 16, 5)])
+def test_epoch_path_on_random_shapes(orc, case, k, W):
+    # random small problems through the epoch path (pre-pass metadata, update launches, fold launches): odd and wide k (all
+    # three register layouts), rounds from single users (a handful of events: fold lists shorter than a wave's group) to more
+    # than the epoch, users without events, a skewed item popularity (staged and hot rows in almost every round).
+    # (case 0 is the shape that exposed a fold-list bug of the wide-k kernel in round 2: tools/experiments/random_shapes_probe.py)
+    from yue_amd._shim import Device
+    rs = np.random.RandomState(1000 + case)
+    m = int(rs.randint(1, 1500)); n = int(rs.randint(50, 4000))
+    P0 = rs.rand(m, k).astype(np.float32) / 10
+    Q0 = rs.rand(n, k).astype(np.float32) / 10
+    pop = 1.0 / (np.arange(n) + 3.0) ** 0.9
+    pop = pop[rs.permutation(n)]; pop /= pop.sum()
+    ev, rows = [], []
+    for u in range(m):
+        cnt = int(rs.randint(0, min(60, n - 1) + 1)) if rs.rand() > 0.1 else 0       # some users have no events
+        it = rs.choice(n, size=cnt, p=pop) if cnt else np.zeros(0, np.int64)
+        ev.append(it.astype(np.int32)); rows.append(np.unique(it).astype(np.int32))
+    ev_ptr = np.cumsum([0] + [len(e) for e in ev]).astype(np.int64)
+    if ev_ptr[-1] == 0:
+        pytest.skip('no events drawn')
+    ev_i = np.concatenate(ev).astype(np.int32)
+    indptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
+    indices = np.concatenate(rows).astype(np.int32)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(ev_ptr))
+    dev = Device(0, raise_errors=True)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(indptr, indices, ev_ptr, ev_i)
+    assert dev.get_option('round_path') == 1
+    Po, Qo = P0.copy(), Q0.copy()
+    rp = np.array(epoch_round_ptr(ev_ptr, W), np.int64)
+    for epoch in range(2):
+        j = orc.sample_counter(77, epoch, ev_u, n, indptr, indices)
+        nll, sp, sq = dev.bpr_epoch(77, epoch, W, 0.03, 0.01, 0.02)
+        nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.03, 0.01, 0.02)
+        P, Q = dev.get_factors()
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (case, m, n, k, W, epoch)
+        assert abs(nll - nll_o) <= 1e-8 * max(abs(nll_o), 1e-30), (case, m, n, k, W, epoch)
+    dev.close()
+
+
 @pytest.mark.parametrize('m,n,k', [(1, 3, 1), (2, 2, 3), (5, 40, 16), (3, 70, 256)])
 def test_degenerate_shapes(orc, m, n, k):
     # smallest and widest supported shapes through every entry point

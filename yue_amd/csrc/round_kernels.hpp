@@ -417,13 +417,20 @@ __global__ void __launch_bounds__(256) k_round_fold(FoldArgs f) {
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     u32x8 ev;
     unsigned long long cntw;
-    const uint2 *first = f.fold + (b0 + 4u <= f.capacity ? b0 : 0u);
+    const bool spec = b0 + 4u <= f.capacity;              // else: too close to the end of the list area, the group is loaded below
+    const uint2 *first = f.fold + (spec ? b0 : 0u);
     // (written out: the compiler would load the count, branch on it, and only then ask for the entries)
     asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(ev), "=&s"(cntw) : "s"(first), "s"(f.round_rows) : "memory");
     const uint32_t cnt = (uint32_t)(cntw >> 32);
     ent[0] = make_uint2(ev[0], ev[1]); ent[1] = make_uint2(ev[2], ev[3]); ent[2] = make_uint2(ev[4], ev[5]); ent[3] = make_uint2(ev[6], ev[7]);
-    if (b0 < cnt) fold_group<KR, EPG>(f, lane, k, min((uint32_t)EPG, cnt - b0), ent);
+    if (b0 < cnt) {
+        if (!spec) {
+#pragma unroll
+            for (int sl = 0; sl < EPG; ++sl) ent[sl] = f.fold[b0 + sl < cnt ? b0 + sl : b0];
+        }
+        fold_group<KR, EPG>(f, lane, k, min((uint32_t)EPG, cnt - b0), ent);
+    }
     for (uint32_t b = b0 + nwaves * EPG; b < cnt; b += nwaves * EPG) {
 #pragma unroll
         for (int sl = 0; sl < EPG; ++sl) ent[sl] = f.fold[b + sl < cnt ? b + sl : b];
