@@ -99,6 +99,35 @@ def test_scan_matches_oracle(dev, orc, m, n, k, N, per_user):
     assert np.array_equal(ids2, ids) and np.array_equal(sc2, sc)
 
 
+@pytest.mark.parametrize('case', range(12))
+def test_scan_on_random_shapes(dev, orc, case):
+    # random shapes through both bf16 kernels and the f32 kernel: users not a multiple of the workgroup, item counts around
+    # the tile / stage boundaries (32, 64), short lists, dense masks, positive and signed factors, trained-like norms
+    rs = np.random.RandomState(500 + case)
+    k = int(rs.choice([16, 32, 64, 128, 128, 24, 200]))
+    N = int(rs.randint(1, 41))
+    n = int(rs.choice([N + 33, 64 * rs.randint(2, 40), 64 * rs.randint(2, 40) + rs.randint(1, 64), rs.randint(N + 40, 6000)]))
+    m = int(rs.randint(1, 700))
+    per_user = int(rs.randint(0, min(200, n - N - 1)))
+    P, Q, indptr, indices = _rand_problem(m, n, k, per_user, seed=900 + case, signed=bool(case % 2))
+    if case % 3 == 0:
+        Q *= rs.rand(n, 1).astype(np.float32) * 3            # uneven item norms: the norm-bound skips and exits take effect
+    dev.set_factors(P, Q)
+    users = rs.permutation(m)[:max(1, int(rs.randint(1, m + 1)))].astype(np.int32)
+    mp, mi = mask_rows(indptr, indices, users)
+    oid, osc, rc = orc.topn_scan(P, Q, users, N, mp, mi)
+    assert rc == 0
+    for batch in (0, 1):
+        dev.set_option('scan_batch', batch)
+        ids, sc = dev.topn_scan(users, N, mp, mi)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc), (case, k, N, n, m, batch)
+    dev.set_option('scan_batch', 0)
+    dev.set_option('scan_f32', 1)
+    ids, sc = dev.topn_scan(users, N, mp, mi)
+    dev.set_option('scan_f32', 0)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc), (case, k, N, n, m, 'f32')
+
+
 def test_true_topn_mode(dev, orc):
     # a real top-N beside the reference's overwrite-scan (which is not one, F4)
     for (m, n, k, N, quant) in [(100, 3000, 128, 20, False), (50, 700, 10, 10, False), (40, 600, 16, 10, True)]:

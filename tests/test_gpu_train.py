@@ -392,7 +392,8 @@ def test_full_size_properties(dev):
 
 
 @pytest.mark.parametrize('case,k,W', [(0, 200, 1), (1, 256, 37), (2, 192, 5), (3, 100, 100000), (4, 33, 100000), (5, 100, 1), (6, 7, 1),
-                                      (7, 33, 37), (8, 128, 4096), (9, 7, 256), (10, 3, 4096), (11, 64, 1000), (12, 16, 5)])
+                                      (7, 33, 37), (8, 128, 4096), (9, 7, 256), (10, 3, 4096), (11, 64, 1000), (12, 16, 5),
+                                      (13, 16, 3000), (14, 64, 20000), (15, 200, 700)])
 def test_epoch_path_on_random_shapes(orc, case, k, W):
     # random small problems through the epoch path (pre-pass metadata, update launches, fold launches): odd and wide k (all
     # three register layouts), rounds from single users (a handful of events: fold lists shorter than a wave's group) to more
@@ -401,6 +402,8 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
     from yue_amd._shim import Device
     rs = np.random.RandomState(1000 + case)
     m = int(rs.randint(1, 1500)); n = int(rs.randint(50, 4000))
+    if case >= 13:
+        n = int(rs.randint(38000, 120000))                   # several item ranges in the pre-pass (one LDS word per row, 37,888 per range)
     P0 = rs.rand(m, k).astype(np.float32) / 10
     Q0 = rs.rand(n, k).astype(np.float32) / 10
     pop = 1.0 / (np.arange(n) + 3.0) ** 0.9
