@@ -436,6 +436,22 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
     dev.close()
 
 
+def test_round_size_may_change_between_epochs_on_one_device(dev, orc):
+    # the pre-pass keeps the round boundaries of the last call on the device: another round size re-uploads them
+    m, n, d, k = 900, 1200, 25, 64
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=31)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    Po, Qo = P0.copy(), Q0.copy()
+    for epoch, W in enumerate([1000, 5000, 1000, 64, 5000]):
+        rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
+        j = orc.sample_counter(4, epoch, ev_u, n, data['indptr'], data['indices'])
+        nll, _, _ = dev.bpr_epoch(4, epoch, W, 0.02, 0.01, 0.01)
+        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+        P, Q = dev.get_factors()
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (epoch, W)
+
+
 @pytest.mark.parametrize('m,n,k', [(1, 3, 1), (2, 2, 3), (5, 40, 16), (3, 70, 256)])
 def test_degenerate_shapes(orc, m, n, k):
     # smallest and widest supported shapes through every entry point
