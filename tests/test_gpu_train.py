@@ -436,6 +436,22 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
     dev.close()
 
 
+def test_one_device_serves_problems_of_different_sizes_in_turn(dev, orc):
+    # the epoch path's buffers (metadata, fold lists, round boundaries, staging rows) follow the uploaded problem
+    for (m, n, d, k, W, seed) in [(300, 500, 10, 32, 256, 1), (2500, 3000, 40, 128, 20000, 2), (50, 4000, 5, 200, 64, 3), (2500, 700, 30, 64, 4096, 4)]:
+        data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=seed)
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        Po, Qo = P0.copy(), Q0.copy()
+        rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
+        for epoch in range(2):
+            j = orc.sample_counter(6, epoch, ev_u, n, data['indptr'], data['indices'])
+            nll, _, _ = dev.bpr_epoch(6, epoch, W, 0.02, 0.01, 0.01)
+            nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+            P, Q = dev.get_factors()
+            assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (m, n, k, W, epoch)
+
+
 def test_round_size_may_change_between_epochs_on_one_device(dev, orc):
     # the pre-pass keeps the round boundaries of the last call on the device: another round size re-uploads them
     m, n, d, k = 900, 1200, 25, 64
