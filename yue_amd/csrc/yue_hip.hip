@@ -351,6 +351,8 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
     // staging rows: two per event of the largest round, addressed with 31-bit byte offsets
     int64_t widest = 0;
     for (int64_t r = 0; r < R; ++r) widest = std::max(widest, bounds[(size_t)r + 1] - bounds[(size_t)r]);
+    // the metadata word keeps a staging row index or a row's touch count in 25 bits: rounds of 2^24 events and more stay on k_round
+    if (widest >= (1ll << 24)) meta = false;
     c->staged = c->opt_round_stage && widest > 0 && (c->n + 2 * widest) * (int64_t)c->k * 4 < (1ll << 31);
     if (c->staged) {
         const size_t need = (size_t)(c->n + 2 * widest) * (size_t)c->k;
