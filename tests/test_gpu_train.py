@@ -420,20 +420,22 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
     indptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
     indices = np.concatenate(rows).astype(np.int32)
     ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(ev_ptr))
-    dev = Device(0, raise_errors=True)
-    dev.set_factors(P0, Q0)
-    dev.set_interactions(indptr, indices, ev_ptr, ev_i)
-    assert dev.get_option('round_path') == 1
-    Po, Qo = P0.copy(), Q0.copy()
     rp = np.array(epoch_round_ptr(ev_ptr, W), np.int64)
-    for epoch in range(2):
-        j = orc.sample_counter(77, epoch, ev_u, n, indptr, indices)
-        nll, sp, sq = dev.bpr_epoch(77, epoch, W, 0.03, 0.01, 0.02)
-        nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.03, 0.01, 0.02)
-        P, Q = dev.get_factors()
-        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (case, m, n, k, W, epoch)
-        assert abs(nll - nll_o) <= 1e-8 * max(abs(nll_o), 1e-30), (case, m, n, k, W, epoch)
-    dev.close()
+    for meta in (1, 0):                                      # the epoch path, and the kernel that counts and retires inside the launch
+        dev = Device(0, raise_errors=True)
+        dev.set_option('round_meta', meta)
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(indptr, indices, ev_ptr, ev_i)
+        assert dev.get_option('round_path') == meta
+        Po, Qo = P0.copy(), Q0.copy()
+        for epoch in range(2):
+            j = orc.sample_counter(77, epoch, ev_u, n, indptr, indices)
+            nll, sp, sq = dev.bpr_epoch(77, epoch, W, 0.03, 0.01, 0.02)
+            nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.03, 0.01, 0.02)
+            P, Q = dev.get_factors()
+            assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (case, m, n, k, W, epoch, meta)
+            assert abs(nll - nll_o) <= 1e-8 * max(abs(nll_o), 1e-30), (case, m, n, k, W, epoch, meta)
+        dev.close()
 
 
 def test_one_device_serves_problems_of_different_sizes_in_turn(dev, orc):
