@@ -166,8 +166,9 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *               path); 0: every contended row goes through float atomics
  *   "round_meta" 1 (default): yue_bpr_epoch takes the touch metadata of all rounds from one pre-pass per epoch
  *               (k_round_meta), round launches without a retire phase (k_round_m) and a fold launch behind each
- *               (k_round_fold) -- item shards of up to 454,656 rows; 0: touches counted and contended rows finished
+ *               (k_round_fold) -- item shards of up to 8.4M rows (above 454,656: touches bucketed by item range first); 0: touches counted and contended rows finished
  *               inside the round launches (k_round, the kernel of yue_bpr_rounds).  Also moves yue_default_round_events.
+ *   "round_bucket" 1: the bucketed pre-pass also for small catalogues (tests)
  *   "fold_blocks" workgroups of the fold launch (default 1536)
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of

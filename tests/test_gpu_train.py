@@ -246,6 +246,27 @@ def test_epoch_metadata_pre_pass_over_several_item_ranges(orc):
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, meta
 
 
+def test_epoch_path_on_a_large_catalogue(orc):
+    # more item rows than the plain pre-pass takes (454,656): a round's touches are bucketed by item range first
+    # (k_round_bucket), 19 ranges of 32,768 rows here; sparse touches (most rows untouched) and a popular head
+    from yue_amd._shim import Device
+    m, n, d, k, W = 20000, 600000, 25, 16, 30000
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=8)
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
+    dev = Device(0, raise_errors=True)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    assert dev.get_option('round_path') == 1
+    Po, Qo = P0.copy(), Q0.copy()
+    for epoch in range(2):
+        j = orc.sample_counter(21, epoch, ev_u, n, data['indptr'], data['indices'])
+        nll, _, _ = dev.bpr_epoch(21, epoch, W, 0.03, 0.01, 0.01)
+        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.03, 0.01, 0.01)
+        P, Q = dev.get_factors()
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), epoch
+    dev.close()
+
+
 def test_default_round_size_is_one_resident_wave_set(orc):
     # round_events = 0 -> yue_default_round_events: a multiple of 1024 that fits the chip's resident workgroups
     # (32 events each at 8 events per wave); the epoch equals the explicit call
@@ -288,8 +309,10 @@ def test_default_round_size_grows_with_the_item_count():
     one = sizes[1000]
     assert one % 1024 == 0
     assert sizes[130000] == one * min(3, 130000 // one) and sizes[200000] == one * min(3, 200000 // one) and sizes[400000] == 3 * one
-    dev = Device(0, raise_errors=True)                           # item shards beyond the pre-pass's range budget stay on k_round
-    dev.set_factors(np.zeros((8, 16), np.float32), np.zeros((500000, 16), np.float32))
+    dev = Device(0, raise_errors=True)                           # large catalogues: bucketed pre-pass, still the epoch path ...
+    dev.set_factors(np.zeros((8, 4), np.float32), np.zeros((500000, 4), np.float32))
+    assert dev.get_option('round_path') == 1
+    dev.set_factors(np.zeros((8, 1), np.float32), np.zeros((9000000, 1), np.float32))     # ... up to 256 ranges of 32,768 rows
     assert dev.get_option('round_path') == 0
     dev.close()
 
@@ -421,9 +444,10 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
     indices = np.concatenate(rows).astype(np.int32)
     ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(ev_ptr))
     rp = np.array(epoch_round_ptr(ev_ptr, W), np.int64)
-    for meta in (1, 0):                                      # the epoch path, and the kernel that counts and retires inside the launch
+    for meta, bucket in ((1, 0), (1, 1), (0, 0)):            # the epoch path (plain / bucketed pre-pass), and the kernel that counts and retires inside the launch
         dev = Device(0, raise_errors=True)
         dev.set_option('round_meta', meta)
+        dev.set_option('round_bucket', bucket)
         dev.set_factors(P0, Q0)
         dev.set_interactions(indptr, indices, ev_ptr, ev_i)
         assert dev.get_option('round_path') == meta
@@ -433,8 +457,8 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
             nll, sp, sq = dev.bpr_epoch(77, epoch, W, 0.03, 0.01, 0.02)
             nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.03, 0.01, 0.02)
             P, Q = dev.get_factors()
-            assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (case, m, n, k, W, epoch, meta)
-            assert abs(nll - nll_o) <= 1e-8 * max(abs(nll_o), 1e-30), (case, m, n, k, W, epoch, meta)
+            assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (case, m, n, k, W, epoch, meta, bucket)
+            assert abs(nll - nll_o) <= 1e-8 * max(abs(nll_o), 1e-30), (case, m, n, k, W, epoch, meta, bucket)
         dev.close()
 
 

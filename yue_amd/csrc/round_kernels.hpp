@@ -71,6 +71,12 @@ struct MetaArgs {
     // Fold list: the contended rows of round r are fold[fold_base(bounds[r], r) ...), (round_rows[r] >> 32) of them --
     // {item row, metadata word with ticket 0} each; a round has at most as many contended rows as events.
     uint2 *fold;
+    // Large catalogues (more ranges than a work item should re-read its round for): the round's touches, bucketed by item
+    // range by k_round_bucket -- {item row, 2 * (event - first event of the round) + (0 positive | 1 negative)} each, the
+    // touches of round r in bk_touch[2 * bounds[r] ...), those of range g from bk_ptr[r * (G + 1) + g] on (offsets relative
+    // to the round's first touch slot).  Null: every work item sweeps the round's events itself.
+    const uint2 *bk_touch;
+    const uint32_t *bk_ptr;
 };
 
 // First entry of round r's list (the round starts at event e0): 16-byte aligned, lists do not overlap.
@@ -81,6 +87,7 @@ __host__ __device__ inline int64_t fold_base(int64_t e0, int64_t r) { return (e0
 // the contended rows, then hand every touch its class / ticket / block.  A work item reads the round's (i, j) twice; ranges
 // of one round run on different CUs.  Tickets follow the order in which the LDS serves the touches, not the event order:
 // the sum of a row's staged differences is taken in ticket order (any order is within the fp32 tolerance of the oracle's).
+template <bool BUCKETED>
 __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
     extern __shared__ uint32_t slots[];
     __shared__ unsigned long long wsum[16];
@@ -99,6 +106,16 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
         const int64_t e0 = a.bounds[r], e1 = a.bounds[r + 1];
         for (int s = tid; s < a.range; s += 1024) slots[s] = 0u;
         __syncthreads();
+        const uint2 *mine_t = nullptr;                      // BUCKETED: this work item's touches
+        uint32_t mine_n = 0u;
+        if (BUCKETED) {
+            const uint32_t *bp = a.bk_ptr + r * (a.G + 1) + g;
+            mine_t = a.bk_touch + 2 * e0 + bp[0];
+            mine_n = bp[1] - bp[0];
+        }
+        if (BUCKETED) {
+            for (uint32_t t = tid; t < mine_n; t += 1024) atomicAdd(&slots[mine_t[t].x - (uint32_t)lo], 1u);
+        } else {
         for (int64_t eb = e0 + tid; eb < e1; eb += 1024 * kMetaUnroll) {
             int32_t vi[kMetaUnroll], vj[kMetaUnroll];
 #pragma unroll
@@ -113,6 +130,7 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
                     if (si < (uint32_t)width) atomicAdd(&slots[si], 1u);
                     if (sj < (uint32_t)width) atomicAdd(&slots[sj], 1u);
                 }
+        }
         }
         __syncthreads();
         // staging rows of this range: the sum of the touch counts of its rows with 2..stage_max touches (low half);
@@ -150,6 +168,16 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
             }
         }
         __syncthreads();
+        if (BUCKETED) {
+            // (events the sampler gave up on carry no touches: k_round_bucket wrote their two zero words)
+            for (uint32_t t = tid; t < mine_n; t += 1024) {
+                const uint2 tc = mine_t[t];
+                const uint32_t sl = tc.x - (uint32_t)lo;
+                const uint32_t wd = slots[sl], cl = meta_class(wd);
+                const uint32_t mw = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[sl], 16u) : wd;
+                ((tc.y & 1u) ? a.meta_j : a.meta_i)[e0 + (tc.y >> 1)] = mw;
+            }
+        } else
         for (int64_t eb = e0 + tid; eb < e1; eb += 1024 * kMetaUnroll) {
             int32_t vi[kMetaUnroll], vj[kMetaUnroll];
 #pragma unroll
@@ -176,6 +204,71 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
                     a.meta_i[e] = 0u; a.meta_j[e] = 0u;
                 }
             }
+        }
+        __syncthreads();
+    }
+}
+
+// Large catalogues: one workgroup per round sorts the round's touches into their item ranges (range = 2^kBucketShift rows:
+// a counting pass and a scatter pass over the round's events, bucket offsets from an LDS prefix sum), so that a work item of
+// k_round_meta<true> reads its own touches only.  Also writes the two zero metadata words of events without a negative.
+constexpr int kBucketShift = 15;
+constexpr int kBucketRangesMax = 256;
+struct BucketArgs {
+    const int32_t *ev_i, *ev_j;
+    const int64_t *bounds;
+    int64_t R;
+    int32_t G;
+    uint2 *bk_touch;
+    uint32_t *bk_ptr;            // [R * (G + 1)]
+    uint32_t *meta_i, *meta_j;
+};
+
+__global__ void __launch_bounds__(1024) k_round_bucket(BucketArgs a) {
+    __shared__ uint32_t cnt[kBucketRangesMax], off[kBucketRangesMax + 1];
+    const int tid = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < a.R; r += gridDim.x) {
+        const int64_t e0 = a.bounds[r], e1 = a.bounds[r + 1];
+        for (int g = tid; g < a.G; g += 1024) cnt[g] = 0u;
+        __syncthreads();
+        for (int64_t eb = e0 + tid; eb < e1; eb += 1024 * kMetaUnroll) {
+            int32_t vi[kMetaUnroll], vj[kMetaUnroll];
+#pragma unroll
+            for (int q = 0; q < kMetaUnroll; ++q) {
+                const int64_t e = eb + 1024 * q;
+                vj[q] = e < e1 ? a.ev_j[e] : 0; vi[q] = e < e1 ? a.ev_i[e] : -1;       // (vi < 0: no such event)
+            }
+#pragma unroll
+            for (int q = 0; q < kMetaUnroll; ++q) {
+                if (vi[q] < 0) continue;
+                if (vj[q] >= 0) { atomicAdd(&cnt[vi[q] >> kBucketShift], 1u); atomicAdd(&cnt[vj[q] >> kBucketShift], 1u); }
+                else { a.meta_i[eb + 1024 * q] = 0u; a.meta_j[eb + 1024 * q] = 0u; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0u;
+            for (int g = 0; g < a.G; ++g) { off[g] = run; run += cnt[g]; cnt[g] = 0u; }
+            off[a.G] = run;
+        }
+        __syncthreads();
+        for (int g = tid; g <= a.G; g += 1024) a.bk_ptr[r * (a.G + 1) + g] = off[g];
+        uint2 *dst = a.bk_touch + 2 * e0;
+        for (int64_t eb = e0 + tid; eb < e1; eb += 1024 * kMetaUnroll) {
+            int32_t vi[kMetaUnroll], vj[kMetaUnroll];
+#pragma unroll
+            for (int q = 0; q < kMetaUnroll; ++q) {
+                const int64_t e = eb + 1024 * q;
+                vj[q] = e < e1 ? a.ev_j[e] : -1; vi[q] = e < e1 ? a.ev_i[e] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < kMetaUnroll; ++q)
+                if (vj[q] >= 0) {
+                    const uint32_t code = 2u * (uint32_t)(eb + 1024 * q - e0);
+                    const int gi = vi[q] >> kBucketShift, gj = vj[q] >> kBucketShift;
+                    dst[off[gi] + atomicAdd(&cnt[gi], 1u)] = make_uint2((uint32_t)vi[q], code);
+                    dst[off[gj] + atomicAdd(&cnt[gj], 1u)] = make_uint2((uint32_t)vj[q], code | 1u);
+                }
         }
         __syncthreads();
     }

@@ -72,7 +72,8 @@ struct yue_ctx {
     // epoch path: touch metadata of all rounds from one pre-pass (round_kernels.hpp)
     DevBuf<uint32_t> meta_i, meta_j;
     DevBuf<unsigned long long> round_rows;
-    DevBuf<uint2> fold;
+    DevBuf<uint2> fold, bk_touch;
+    DevBuf<uint32_t> bk_ptr;
     DevBuf<int64_t> d_bounds;
     std::vector<int64_t> h_bounds;               // outlives the asynchronous upload
 #ifdef YUE_STAMPS
@@ -101,6 +102,7 @@ struct yue_ctx {
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 2..4: rows with up to that many touches are staged (epoch path)
+    int opt_round_bucket = 0;            // 1: the bucketed pre-pass also for small catalogues (tests)
     int opt_fold_blocks = 1536;           // workgroups of k_round_fold
     int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
     // kernel timing
@@ -174,7 +176,10 @@ constexpr int64_t kMetaRangeMax = 37 * 1024;       // 148 KB of the CU's 160 KB 
 constexpr int64_t kMetaRangesMax = 12;
 constexpr int64_t kRoundGenerationsMax = 3;
 
-bool meta_path_fits(const yue_ctx *c) { return c->opt_round_meta && c->n <= kMetaRangeMax * kMetaRangesMax; }
+// Larger catalogues (up to kBucketRangesMax ranges of 2^kBucketShift rows = 8.4M item rows per GPU) sort a round's touches into
+// their ranges first (k_round_bucket), so that a work item reads its own touches only.
+bool meta_bucketed(const yue_ctx *c) { return c->n > kMetaRangeMax * kMetaRangesMax || c->opt_round_bucket; }
+bool meta_path_fits(const yue_ctx *c) { return c->opt_round_meta && c->n <= ((int64_t)yue::kBucketRangesMax << yue::kBucketShift); }
 bool fold_path(const yue_ctx *c) { return meta_path_fits(c); }
 
 // Default round size.
@@ -279,19 +284,37 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
     HIPCHK(c->fold.resize((size_t)(E + 4 * R + 8)));
     yue::MetaArgs ma{};
     ma.ev_i = a.ev_i; ma.ev_j = a.ev_j; ma.bounds = c->d_bounds.p; ma.R = R; ma.n = (int32_t)c->n;
-    ma.G = (int32_t)((c->n + kMetaRangeMax - 1) / kMetaRangeMax);
-    ma.range = (int32_t)((c->n + ma.G - 1) / ma.G);
+    const bool bucketed = meta_bucketed(c);
+    if (bucketed) {
+        ma.range = 1 << yue::kBucketShift;
+        ma.G = (int32_t)((c->n + ma.range - 1) >> yue::kBucketShift);
+        HIPCHK(c->bk_touch.resize((size_t)(2 * E + 2))); HIPCHK(c->bk_ptr.resize((size_t)R * (ma.G + 1)));
+        yue::BucketArgs ba{};
+        ba.ev_i = a.ev_i; ba.ev_j = a.ev_j; ba.bounds = c->d_bounds.p; ba.R = R; ba.G = ma.G;
+        ba.bk_touch = c->bk_touch.p; ba.bk_ptr = c->bk_ptr.p; ba.meta_i = c->meta_i.p; ba.meta_j = c->meta_j.p;
+        int cus0 = 0;
+        HIPCHK(hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, c->device));
+        hipLaunchKernelGGL(yue::k_round_bucket, dim3((unsigned)std::min<int64_t>(R, 2 * cus0)), dim3(1024), 0, c->stream, ba);
+        ma.bk_touch = c->bk_touch.p; ma.bk_ptr = c->bk_ptr.p;
+    } else {
+        ma.G = (int32_t)((c->n + kMetaRangeMax - 1) / kMetaRangeMax);
+        ma.range = (int32_t)((c->n + ma.G - 1) / ma.G);
+    }
     ma.chunk = (ma.range + 1023) / 1024; ma.chunk |= 1;
     ma.stage_max = !c->staged ? 1u : c->opt_round_stage >= 2 ? (uint32_t)c->opt_round_stage : yue::kMetaStageMax;
     ma.meta_i = c->meta_i.p; ma.meta_j = c->meta_j.p; ma.round_rows = c->round_rows.p; ma.fold = c->fold.p;
     const size_t lds = (size_t)ma.range * sizeof(uint32_t);
-    HIPCHK(hipFuncSetAttribute((const void *)yue::k_round_meta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *kfn = bucketed ? (const void *)yue::k_round_meta<true> : (const void *)yue::k_round_meta<false>;
+    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0, cus = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_meta, 1024, lds));
+    if (bucketed) { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_meta<true>, 1024, lds)); }
+    else { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_round_meta<false>, 1024, lds)); }
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     // a multiple of 8 workgroups (k_round_meta deals the work out per XCD), at most one resident set
     const int64_t grid = std::max<int64_t>(8, std::min<int64_t>((R * ma.G + 7) / 8 * 8, (int64_t)std::max(per_cu, 1) * cus / 8 * 8));
-    hipLaunchKernelGGL(yue::k_round_meta, dim3((unsigned)grid), dim3(1024), lds, c->stream, ma);
+    if (bucketed) hipLaunchKernelGGL(yue::k_round_meta<true>, dim3((unsigned)grid), dim3(1024), lds, c->stream, ma);
+    else
+        hipLaunchKernelGGL(yue::k_round_meta<false>, dim3((unsigned)grid), dim3(1024), lds, c->stream, ma);
     HIPCHK(hipGetLastError());
     return YUE_OK;
 }
@@ -510,7 +533,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->tab0.release(); c->tab1.release();
-    c->meta_i.release(); c->meta_j.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release();
+    c->meta_i.release(); c->meta_j.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release(); c->bk_touch.release(); c->bk_ptr.release();
     c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
     c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
     c->aU_m.release(); c->aU_v.release(); c->aV_m.release(); c->aV_v.release();
@@ -913,6 +936,7 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "topn_true") *value = c->opt_topn_true;
     else if (key == "round_stage") *value = c->opt_round_stage;
     else if (key == "round_meta") *value = c->opt_round_meta;
+    else if (key == "round_bucket") *value = c->opt_round_bucket;
     else if (key == "fold_blocks") *value = c->opt_fold_blocks;
     else if (key == "round_tpw") *value = c->opt_round_tpw;
     // which kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_meta + k_round_m + k_round_fold
@@ -932,6 +956,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
         c->opt_round_stage = (int)value; return YUE_OK;
     }
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
+    if (key == "round_bucket") { c->opt_round_bucket = value != 0; return YUE_OK; }
     if (key == "fold_blocks") { if (value < 1 || value > 65536) return fail(YUE_ERR_ARG, "yue_set_option: fold_blocks out of range"); c->opt_fold_blocks = (int)value; return YUE_OK; }
 #ifdef YUE_STAMPS
     if (key == "debug_stamp_launch") { c->stamp_launch = value; c->update_launches = 0; return YUE_OK; }
