@@ -37,6 +37,8 @@ WORKLOADS = {
     'c3': (1000000, 200000, 50, 128),
     'c2': (100000, 50000, 50, 64),
     'tiny': (20000, 5000, 20, 128),
+    # a catalogue beyond the plain pre-pass (454,656 item rows): C3's users and events on 1M items (bucketed pre-pass)
+    'c3wide': (1000000, 1000000, 50, 128),
     # one GPU's share of BASELINE config 4 (10M users x 1M items over 8 GPUs): replicated 5.1 GB of user factors,
     # a 125K-item shard, 60M of the 500M events; run with --force-comm to take the all-reduce path on one rank
     'c4shard': (10000000, 125000, 6, 128),
