@@ -8,7 +8,7 @@
     60M events) through the communicator code path (1-rank RCCL communicator: all-reduce + range apply
     on the second stream) against the same oracle (world = 1: the sharded spec IS the S-round oracle
     with rounds cut at user blocks, tests/test_dist_cpu.py::test_one_rank_spec_equals_plain_rounds);
-  * config 2 (100K x 50K, k=64): how far one S-round epoch (the throughput semantics) lands from the
+  * config 3 and config 2 (100K x 50K, k=64): how far one S-round epoch (the throughput semantics) lands from the
     reference's strictly sequential loop (recommender/cf/BPR.py:40-62, orc_bpr_sequential) on the same
     negatives -- the semantic deviation, with a stated bound.
 
@@ -91,6 +91,43 @@ def test_config4_shard_through_the_communicator_path(orc):
         _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'C4 shard (communicator path)')
     finally:
         dev.close()
+
+
+def _round_semantics_vs_sequential(orc, m, n, d, k, tag):
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    E = len(ev_u)
+    dev = _fresh_device()
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        W = dev.default_round_events()
+        j = dev.sample_negatives(20260003, 0)
+        nll_r, _, _ = dev.bpr_epoch(20260003, 0, W, LR, REG_U, REG_I)
+        Pr, Qr = dev.get_factors()
+    finally:
+        dev.close()
+    Ps, Qs = P0.copy(), Q0.copy()
+    nll_s = orc.bpr_sequential(Ps, Qs, ev_u, data['ev_i'], j, LR, REG_U, REG_I)
+
+    def rms(a):
+        return float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+    moved_P, moved_Q = rms(Ps - P0), rms(Qs - Q0)
+    dist_P, dist_Q = rms(Pr - Ps), rms(Qr - Qs)
+    dloss = abs(nll_r - nll_s) / nll_s
+    print('%s, one epoch, W=%d: nll/triplet sequential %.6f  S-round %.6f  (rel diff %.2e);  RMS distance S-round vs sequential '
+          'P %.3e Q %.3e  against RMS movement of the epoch P %.3e Q %.3e  (ratio P %.3f Q %.3f);  norm-wise rel P %.2e Q %.2e'
+          % (tag, W, nll_s / E, nll_r / E, dloss, dist_P, dist_Q, moved_P, moved_Q, dist_P / moved_P, dist_Q / moved_Q,
+             rel_err(Pr, Ps), rel_err(Qr, Qs)))
+    return dloss, dist_P / moved_P, dist_Q / moved_Q
+
+
+def test_config3_round_semantics_vs_the_sequential_loop(orc):
+    # the bench workload itself: one epoch of the throughput semantics at the default W (172,032 events per round) against the
+    # reference's strictly sequential loop on identical negatives (50M triplets through the C oracle: under a minute)
+    dloss, rP, rQ = _round_semantics_vs_sequential(orc, 1000000, 200000, 50, 128, 'C3')
+    assert dloss < 1e-2 and rP < 0.25 and rQ < 0.25
 
 
 def test_config2_round_semantics_vs_the_sequential_loop(orc):
