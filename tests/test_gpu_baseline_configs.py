@@ -133,34 +133,7 @@ def test_config3_round_semantics_vs_the_sequential_loop(orc):
 def test_config2_round_semantics_vs_the_sequential_loop(orc):
     # How far does ONE epoch of the throughput semantics (S-round, default W) land from the reference's strictly
     # sequential loop on identical negatives?  Both start from the same factors; the distance is compared with
-    # the distance the epoch itself travels.
-    m, n, d, k = 100000, 50000, 50, 64
-    data = synth.make_arrays(m, n, d, seed=20260001)
-    P0, Q0 = synth.init_factors(m, n, k, 20260002)
-    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
-    E = len(ev_u)
-    dev = _fresh_device()
-    try:
-        dev.set_factors(P0, Q0)
-        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
-        W = dev.default_round_events()
-        j = dev.sample_negatives(20260003, 0)
-        nll_r, _, _ = dev.bpr_epoch(20260003, 0, W, LR, REG_U, REG_I)
-        Pr, Qr = dev.get_factors()
-    finally:
-        dev.close()
-    Ps, Qs = P0.copy(), Q0.copy()
-    nll_s = orc.bpr_sequential(Ps, Qs, ev_u, data['ev_i'], j, LR, REG_U, REG_I)
-
-    def rms(a):
-        return float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
-    moved_P, moved_Q = rms(Ps - P0), rms(Qs - Q0)
-    dist_P, dist_Q = rms(Pr - Ps), rms(Qr - Qs)
-    dloss = abs(nll_r - nll_s) / nll_s
-    print('C2, one epoch, W=%d: nll/triplet sequential %.6f  S-round %.6f  (rel diff %.2e);  RMS distance S-round vs sequential '
-          'P %.3e Q %.3e  against RMS movement of the epoch P %.3e Q %.3e  (ratio P %.3f Q %.3f);  norm-wise rel P %.2e Q %.2e'
-          % (W, nll_s / E, nll_r / E, dloss, dist_P, dist_Q, moved_P, moved_Q, dist_P / moved_P, dist_Q / moved_Q,
-             rel_err(Pr, Ps), rel_err(Qr, Qs)))
-    # stated bounds: the epoch's loss within 1 %, and the two end points much closer to each other than either is to the start
-    assert dloss < 1e-2
-    assert dist_P < 0.25 * moved_P and dist_Q < 0.25 * moved_Q
+    # the distance the epoch itself travels.  Stated bounds: the epoch's loss within 1 %, and the two end points much
+    # closer to each other than either is to the start.
+    dloss, rP, rQ = _round_semantics_vs_sequential(orc, 100000, 50000, 50, 64, 'C2')
+    assert dloss < 1e-2 and rP < 0.25 and rQ < 0.25
