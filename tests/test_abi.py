@@ -52,16 +52,16 @@ def test_product_never_imports_oracle():
 
 
 def test_round_kernels_fit_the_residency_the_host_assumes(tmp_path):
-    """default_round_events (csrc/yue_hip.hip) sizes a round for 7 resident workgroups per CU of k_round_m and 6 of k_round:
+    """default_round_events (csrc/bpr_host.hip) sizes a round for 7 resident workgroups per CU of k_round_m and 6 of k_round:
     that holds while the kernels stay within 96 / 112 allocated SGPRs and 72 / 80 VGPRs without scratch (MI355X residency
     rule: floor(800 / (SGPRs rounded up to 16 + 16)) workgroups of 4 waves, 512 VGPRs per SIMD).  Compiles the device code
     once more with the compiler's resource remarks (about a minute)."""
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    src = os.path.join(ROOT, 'yue_amd', 'csrc', 'yue_hip.hip')
+    src = os.path.join(ROOT, 'yue_amd', 'csrc', 'bpr_host.hip')
     out = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S', '--cuda-device-only',
-                          '-Rpass-analysis=kernel-resource-usage', '-o', str(tmp_path / 'yue_hip.s'), src],
+                          '-Rpass-analysis=kernel-resource-usage', '-o', str(tmp_path / 'bpr_host.s'), src],
                          capture_output=True, text=True, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
     usage = {}

@@ -1,0 +1,132 @@
+"""GPU parity of the EXACT training path (chain_kernels.hpp: the reference's sequential loop, recommender/cf/BPR.py:40-62,
+as a dataflow launch), through the C ABI.  Checker: oracle/bpr_oracle.c: orc_bpr_sequential (pinned to the reference by
+tests/test_oracle_golden.py) and the reference's own golden factors.  Same dot order on both sides: differences can only come
+from exp / log last-bit rounding, so the bound is 1e-6 (north_star: 1e-5 rel)."""
+import numpy as np
+import pytest
+
+from yue_amd import synth
+from util import gz, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from yue_amd._shim import Device
+    d = Device(0, raise_errors=True)
+    yield d
+    d.close()
+
+
+def _problem(m, n, d, k, seed):
+    data = synth.make_arrays(m, n, d, seed=seed)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    P0, Q0 = synth.init_factors(m, n, k, seed + 1)
+    return data, ev_u, P0, Q0
+
+
+@pytest.mark.parametrize('m,n,d,k', [(3000, 2000, 20, 128), (5000, 64, 12, 64), (700, 900, 30, 10), (400, 300, 25, 200), (20000, 5000, 20, 128)])
+def test_exact_epoch_equals_the_sequential_loop(dev, orc, m, n, d, k):
+    """yue_bpr_epoch with option epoch_exact: the device sampler's negatives, applied strictly in the reference's order.
+    (5000 users on 64 items: every row is hot, the whole epoch is a handful of long chains.)"""
+    data, ev_u, P0, Q0 = _problem(m, n, d, k, 31 + k)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    dev.set_option('epoch_exact', 1)
+    try:
+        Po, Qo = P0.copy(), Q0.copy()
+        for ep in range(2):
+            j = dev.sample_negatives(5, ep)
+            nll, sp, sq = dev.bpr_epoch(5, ep, 0, 0.02, 0.01, 0.01)
+            nll_o = orc.bpr_sequential(Po, Qo, ev_u, data['ev_i'], j, 0.02, 0.01, 0.01)
+            assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+        P, Q = dev.get_factors()
+        assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6
+        assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp and abs(sq - orc.sumsq(Q)) <= 1e-12 * sq
+        print('bit-equal to the oracle: P %.4f Q %.4f; runs %d on %d waves' % (np.mean(P == Po), np.mean(Q == Qo), dev.get_option('chain_last_runs'), dev.get_option('chain_last_waves')))
+    finally:
+        dev.set_option('epoch_exact', 0)
+
+
+def test_replay_of_an_interleaved_stream(dev, orc):
+    """yue_bpr_replay on a stream that is NOT user-major: users come back in later runs (user rows versioned per run), items
+    repeat inside a run, some triplets are skipped (j < 0)."""
+    rs = np.random.RandomState(77)
+    m, n, k, T = 300, 500, 64, 40000
+    P0, Q0 = synth.init_factors(m, n, k, 78)
+    u = rs.randint(0, m, size=T).astype(np.int32)
+    u[1000:1400] = 7                                       # one long run
+    idx = np.arange(0, T - 1, 3)
+    u[idx] = u[idx + 1]                                    # many runs of two
+    i = (n * rs.rand(T) ** 2).astype(np.int32)              # skewed positives
+    j = rs.randint(0, n, size=T).astype(np.int32)
+    j[j == i] = (i[j == i] + 1) % n
+    j[rs.rand(T) < 0.01] = -1
+    dev.set_factors(P0, Q0)
+    nll = dev.bpr_replay(u, i, j, 0.03, 0.02, 0.01)
+    Po, Qo = P0.copy(), Q0.copy()
+    nll_o = orc.bpr_sequential(Po, Qo, u, i, j, 0.03, 0.02, 0.01)
+    P, Q = dev.get_factors()
+    assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    assert rel_err(P, Po) < 1e-6 and rel_err(Q, Qo) < 1e-6
+    # the levelled replay of round 1 (one launch per dependency level) lands on the same factors
+    dev.set_factors(P0, Q0)
+    dev.set_option('replay_levels', 1)
+    try:
+        nll_l = dev.bpr_replay(u, i, j, 0.03, 0.02, 0.01)
+        levels = dev.get_option('replay_last_levels')
+    finally:
+        dev.set_option('replay_levels', 0)
+    Pl, Ql = dev.get_factors()
+    assert np.array_equal(P, Pl) and np.array_equal(Q, Ql) and abs(nll_l - nll) <= 1e-9 * abs(nll)
+    print('dependency levels of the stream: %d' % levels)
+
+
+def test_exact_path_on_the_reference_goldens(dev):
+    """Two epochs of the reference's own run (k = 128): the factors the reference's NumPy loop produced, within 1e-5."""
+    z = gz('g4_d3_k128_e2.npz')
+    iters = int(z['iters'])
+    E = len(z['u']) // iters
+    P0, Q0 = synth.init_factors(int(z['m']), int(z['n']), int(z['k']), int(z['seed']))
+    dev.set_factors(P0, Q0)
+    for ep in range(iters):
+        sl = slice(ep * E, (ep + 1) * E)
+        dev.bpr_replay(z['u'][sl], z['i'][sl], z['j'][sl], 0.02, 0.01, 0.01)
+    P, Q = dev.get_factors()
+    assert rel_err(P, z['P']) < 1e-5 and rel_err(Q, z['Q']) < 1e-5
+
+
+def test_exact_path_rejects_bad_streams_before_touching_the_factors(dev):
+    from yue_amd._shim import YueHipError
+    P0, Q0 = synth.init_factors(50, 40, 16, 3)
+    dev.set_factors(P0, Q0)
+    good = (np.array([1, 1, 2], np.int32), np.array([3, 4, 5], np.int32), np.array([6, 7, 8], np.int32))
+    for bad in [(np.array([1, 50, 2], np.int32), good[1], good[2]),             # user out of range
+                (good[0], np.array([3, 40, 5], np.int32), good[2]),             # item out of range
+                (good[0], good[1], np.array([6, 4, 8], np.int32)),              # i == j
+                (good[0], good[1], np.array([6, 7, 41], np.int32))]:
+        with pytest.raises(YueHipError):
+            dev.bpr_replay(bad[0], bad[1], bad[2], 0.05, 0.02, 0.03)
+        P, Q = dev.get_factors()
+        assert np.array_equal(P, P0) and np.array_equal(Q, Q0)
+    assert dev.bpr_replay(*good, 0.05, 0.02, 0.03) > 0.0
+
+
+def test_a_wave_that_cannot_get_its_row_gives_up_instead_of_hanging(dev):
+    """The guard behind every wait: with a spin limit of a few polls a contended epoch must come back with an error, not hang
+    (and the device must serve the next call)."""
+    from yue_amd._shim import YueHipError
+    data, ev_u, P0, Q0 = _problem(4000, 8, 6, 64, 5)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    dev.set_option('epoch_exact', 1)
+    dev.set_option('chain_spin', 2)
+    try:
+        with pytest.raises(YueHipError):
+            dev.bpr_epoch(5, 0, 0, 0.02, 0.01, 0.01)
+    finally:
+        dev.set_option('chain_spin', 0)
+        dev.set_option('epoch_exact', 0)
+    dev.set_factors(P0, Q0)
+    assert np.isfinite(dev.bpr_epoch(5, 0, 512, 0.02, 0.01, 0.01)[0])

@@ -1,138 +1,15 @@
-// libyue_hip.so -- C ABI (include/yue_hip.h) over the gfx950 kernels.
-// Host side: device buffers behind an opaque context, dependency levelling for exact replay,
-// round scheduling of an epoch, RCCL all-reduce of user-factor differences.
-#include "../../include/yue_hip.h"
-
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+// libyue_hip.so -- BPR training entry points: exact replay by dependency levels, S-rounds, fused epochs, CUNE's steps, the
+// TF-style Adam step, options and kernel timing (include/yue_hip.h).
+#include "host_common.hpp"
 
 #include "train_kernels.hpp"
 #include "round_kernels.hpp"
-#include "score_kernels.hpp"
-#include "fism_kernels.hpp"
+
+using yue_host::fail;
+using yue_host::kr_of;
+static_assert(yue::kNllSlots == yue_host::kNllSlotsHost && yue::kHeaderSlack == yue_host::kHeaderSlackHost, "host_common.hpp mirrors these");
 
 namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) { g_err = msg; return code; }
-
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(YUE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
-    } while (0)
-
-#define NCCLCHK(expr)                                                                             \
-    do {                                                                                          \
-        ncclResult_t r_ = (expr);                                                                 \
-        if (r_ != ncclSuccess)                                                                    \
-            return fail(YUE_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));        \
-    } while (0)
-
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    hipError_t resize(size_t count) {
-        if (count <= n && p) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; n = 0; if (e != hipSuccess) return e; }
-        if (count == 0) return hipSuccess;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
-}  // namespace
-
-struct yue_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int64_t m = 0, n = 0, E = 0, nnz = 0;
-    int k = 0;
-    bool have_factors = false, have_inter = false;
-    DevBuf<float> P, Q, dP, dQ;
-    DevBuf<unsigned long long> cnt0, cnt1;       // item-row touch counters of the even / odd round (total | remaining)
-    DevBuf<uint32_t> cntp0, cntp1;               // user-row flushes of the even / odd round
-    DevBuf<uint32_t> tab0, tab1;                 // staging-slot tables of the even / odd round (kStageMax words per item row)
-    // staged item rows (2 per event of the widest round) live behind the n item rows in the Q allocation,
-    // so that "new row in place" and "new row to my staging row" are the same store with another offset
-    bool staged = false;                         // the running call uses the staging rows
-    // epoch path: touch metadata of all rounds from one pre-pass (round_kernels.hpp)
-    DevBuf<uint32_t> meta_i, meta_j;
-    DevBuf<unsigned long long> round_rows;
-    DevBuf<uint2> fold, bk_touch;
-    DevBuf<uint32_t> bk_ptr;
-    DevBuf<int64_t> d_bounds;
-    std::vector<int64_t> h_bounds;               // outlives the asynchronous upload
-#ifdef YUE_STAMPS
-    DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
-    int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0;
-#endif
-    DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
-    DevBuf<int64_t> indptr;
-    DevBuf<int32_t> xu, xi, xj, xk;      // explicit triplets (replay / rounds), CUNE's fourth row
-    DevBuf<double> x_loss;               // per-step losses (CUNE)
-    DevBuf<float> aU_m, aU_v, aV_m, aV_v;  // Adam moments of the live TF-style path (yue_adam_step); gradients use dP / dQ
-    int64_t adam_m = 0, adam_n = 0; int adam_k = 0;
-    DevBuf<double> scal;                 // [kNllSlots] nll slots + [8] scalars
-    std::vector<int64_t> h_ev_ptr;       // host copy: user -> first event
-    // scoring scratch
-    DevBuf<int32_t> s_users, s_ids, s_mask_idx, s_flags;
-    DevBuf<int64_t> s_mask_ptr;
-    DevBuf<float> s_scores, s_row, s_norms;
-    double scan_ms = 0.0;
-    int64_t scan_events = 0, scan_rescored = 0, scan_tiles_done = 0, scan_tiles_total = 0;
-    DevBuf<unsigned long long> s_work;
-    int scan_used_bf16 = 0;
-    // options (yue_set_option)
-    int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
-    int opt_scan_batch = 0;              // bf16 scoring kernel: 0 = two tiles per iteration, 256 users per workgroup (default); 1 = one tile, 128 users
-    int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
-    int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
-    int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 2..4: rows with up to that many touches are staged (epoch path)
-    int opt_round_bucket = 0;            // 1: the bucketed pre-pass also for small catalogues (tests)
-    int opt_fold_blocks = 1536;           // workgroups of k_round_fold
-    int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
-    // kernel timing
-    int timing_stride = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    std::vector<int64_t> ev_triplets, ev_launches;
-    size_t ev_used = 0;
-    // FISM (parity path): item-history factors (f64), item factors (f32), item bias (f64)
-    DevBuf<double> fP, fBi, f_coef, f_x, f_hist, f_scores, f_out_sc;
-    DevBuf<float> fQ;
-    DevBuf<int64_t> f_ptr;
-    DevBuf<int32_t> f_items, f_negs, f_ids, f_flags;
-    // FISM rounds: touched-item lists, positions, working copies, difference buffers
-    DevBuf<int64_t> f_uq_ptr, f_neg_ptr;
-    DevBuf<int32_t> f_uq_items, f_loc_i, f_loc_j;
-    DevBuf<float> f_wq, f_dQ;
-    DevBuf<double> f_wp, f_wb, f_dP, f_dB;
-    int64_t fn = 0;
-    int fk = 0;
-    // RCCL
-    ncclComm_t comm = nullptr;
-    int rank = 0, nranks = 1;
-    hipStream_t comm_stream = nullptr;   // (all-reduce +) user-row apply of yue_bpr_epoch run here, beside the next rounds
-    hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
-    hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr;      // brackets of the scoring kernel (yue_get_scan_stats)
-};
-
-namespace {
-
-int kr_of(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : 4; }   // registers per lane per row (64 lanes)
 
 yue::TrainArgs make_args(yue_ctx *c, double lr, double regU, double regI) {
     yue::TrainArgs a{};
@@ -449,6 +326,10 @@ void reset_round_state(yue_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
 }
 
+
+}  // namespace
+
+namespace yue_host {
 int zero_scalars(yue_ctx *c) {
     HIPCHK(hipMemsetAsync(c->scal.p, 0, (yue::kNllSlots + 8) * sizeof(double), c->stream));
     return YUE_OK;
@@ -474,8 +355,8 @@ int sumsq_async(yue_ctx *c) {
     return YUE_OK;
 }
 
-int upload_triplets(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T) {
-    for (int64_t t = 0; t < T; ++t) {
+int upload_triplets(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T, bool validate) {
+    for (int64_t t = 0; validate && t < T; ++t) {
         if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] >= c->n)
             return fail(YUE_ERR_ARG, "triplet " + std::to_string(t) + " out of range");
     }
@@ -485,154 +366,25 @@ int upload_triplets(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_
     HIPCHK(hipMemcpyAsync(c->xj.p, j, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     return YUE_OK;
 }
-
-}  // namespace
+}  // namespace yue_host
+using yue_host::zero_scalars; using yue_host::read_scalars; using yue_host::sumsq_async; using yue_host::upload_triplets;
 
 extern "C" {
-
-const char *yue_last_error(void) { return g_err.c_str(); }
-int yue_version(void) { return 1; }
-
-int yue_ctx_create(int device, yue_ctx **out) {
-    if (!out) return fail(YUE_ERR_ARG, "yue_ctx_create: out is NULL");
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (ndev <= 0) return fail(YUE_ERR_HIP, "no HIP device visible: libyue_hip needs an MI355X (no CPU fallback exists)");
-    if (device < 0 || device >= ndev) return fail(YUE_ERR_ARG, "device ordinal out of range");
-    HIPCHK(hipSetDevice(device));
-    yue_ctx *c = new yue_ctx();
-    c->device = device;
-    const auto init = [c]() -> int {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
-        HIPCHK(hipEventCreate(&c->ev_scan0));
-        HIPCHK(hipEventCreate(&c->ev_scan1));
-        HIPCHK(c->scal.resize(yue::kNllSlots + 8));
-        return YUE_OK;
-    };
-    const int rc = init();
-    if (rc) { const std::string msg = g_err; (void)yue_ctx_destroy(c); g_err = msg; return rc; }     // nothing of a half-built context survives
-    *out = c;
-    return YUE_OK;
-}
-
-int yue_ctx_destroy(yue_ctx *c) {
-    if (!c) return YUE_OK;
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
-    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
-    if (c->ev_rounds) (void)hipEventDestroy(c->ev_rounds);
-    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
-    if (c->ev_scan0) (void)hipEventDestroy(c->ev_scan0);
-    if (c->ev_scan1) (void)hipEventDestroy(c->ev_scan1);
-    for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
-    c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
-    c->tab0.release(); c->tab1.release();
-    c->meta_i.release(); c->meta_j.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release(); c->bk_touch.release(); c->bk_ptr.release();
-    c->ev_u.release(); c->ev_i.release(); c->ev_j.release(); c->indices.release(); c->indptr.release();
-    c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
-    c->aU_m.release(); c->aU_v.release(); c->aV_m.release(); c->aV_v.release();
-    c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
-    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release(); c->s_work.release();
-    c->fP.release(); c->fBi.release(); c->f_coef.release(); c->f_x.release(); c->f_hist.release(); c->f_scores.release();
-    c->f_out_sc.release(); c->fQ.release(); c->f_ptr.release(); c->f_items.release(); c->f_negs.release(); c->f_ids.release(); c->f_flags.release();
-    c->f_uq_ptr.release(); c->f_neg_ptr.release(); c->f_uq_items.release(); c->f_loc_i.release(); c->f_loc_j.release();
-    c->f_wq.release(); c->f_dQ.release(); c->f_wp.release(); c->f_wb.release(); c->f_dP.release(); c->f_dB.release();
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
-    return YUE_OK;
-}
-
-int yue_sync(yue_ctx *c) {
-    if (!c) return fail(YUE_ERR_ARG, "null context");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return YUE_OK;
-}
-
-int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64_t n, int k) {
-    if (!c || !P || !Q) return fail(YUE_ERR_ARG, "yue_set_factors: null argument");
-    if (m <= 0 || n <= 0 || k <= 0 || k > 256) return fail(YUE_ERR_ARG, "yue_set_factors: need m,n > 0 and 1 <= k <= 256");
-    if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: ids must fit int32");
-    if (n * (int64_t)k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: the item matrix of one GPU must stay below 2 GiB (n*k*4 < 2^31): shard the items");
-    HIPCHK(hipSetDevice(c->device));
-    if (c->have_inter && (m != c->m || n != c->n || k != c->k)) c->have_inter = false;   // new shape (k enters the offset bounds checked by yue_set_interactions): upload the interactions again
-    if (k != c->k) c->opt_round_tpw = 0;                   // the events-per-wave option was validated against the old k
-    c->m = m; c->n = n; c->k = k;
-    HIPCHK(c->P.resize(m * k)); HIPCHK(c->Q.resize(n * k));
-    HIPCHK(c->dP.resize(m * k)); HIPCHK(c->dQ.resize(n * k));
-    HIPCHK(c->cnt0.resize(n)); HIPCHK(c->cnt1.resize(n)); HIPCHK(c->cntp0.resize(m)); HIPCHK(c->cntp1.resize(m));
-    HIPCHK(hipMemcpyAsync(c->P.p, P, m * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->Q.p, Q, n * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->dP.p, 0, m * k * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->dQ.p, 0, n * k * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->cntp0.p, 0, m * sizeof(uint32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->cntp1.p, 0, m * sizeof(uint32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->cnt0.p, 0, n * sizeof(unsigned long long), c->stream));
-    HIPCHK(hipMemsetAsync(c->cnt1.p, 0, n * sizeof(unsigned long long), c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->have_factors = true;
-    return YUE_OK;
-}
-
-int yue_get_factors(yue_ctx *c, float *P, float *Q) {
-    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_get_factors: no factors uploaded");
-    HIPCHK(hipSetDevice(c->device));
-    if (P) HIPCHK(hipMemcpyAsync(P, c->P.p, c->m * c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (Q) HIPCHK(hipMemcpyAsync(Q, c->Q.p, c->n * c->k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return YUE_OK;
-}
-
-int yue_set_interactions(yue_ctx *c, const int64_t *indptr, const int32_t *indices, const int64_t *ev_ptr, const int32_t *ev_i) {
-    if (!c || !indptr || !indices || !ev_ptr || !ev_i) return fail(YUE_ERR_ARG, "yue_set_interactions: null argument");
-    if (!c->have_factors) return fail(YUE_ERR_ARG, "yue_set_interactions: call yue_set_factors first (m, n)");
-    HIPCHK(hipSetDevice(c->device));
-    const int64_t m = c->m, n = c->n;
-    if (indptr[0] != 0 || ev_ptr[0] != 0) return fail(YUE_ERR_ARG, "yue_set_interactions: indptr[0] and ev_ptr[0] must be 0");
-    for (int64_t u = 0; u < m; ++u) {
-        if (indptr[u + 1] < indptr[u] || ev_ptr[u + 1] < ev_ptr[u]) return fail(YUE_ERR_ARG, "yue_set_interactions: offsets must be non-decreasing");
-        for (int64_t t = indptr[u]; t < indptr[u + 1]; ++t) {
-            if (indices[t] < 0 || indices[t] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: item id out of range");
-            if (t > indptr[u] && indices[t] <= indices[t - 1]) return fail(YUE_ERR_ARG, "yue_set_interactions: rows must be sorted and unique");
-        }
-        if (indptr[u + 1] - indptr[u] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: a user listened to every item (the reference's sampler would never return, BPR.py:47)");
-    }
-    const int64_t nnz = indptr[m], E = ev_ptr[m];
-    {   // the update kernel addresses P relative to a batch's first user with 31-bit byte offsets
-        int64_t prev = -1, max_gap = 0;
-        for (int64_t u = 0; u < m; ++u) if (ev_ptr[u + 1] > ev_ptr[u]) { if (prev >= 0) max_gap = std::max(max_gap, u - prev); prev = u; }
-        if (max_gap * c->k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_interactions: more than 2 GiB of user-factor rows between two consecutive users with events");
-    }
-    std::vector<int32_t> evu((size_t)E);
-    for (int64_t u = 0; u < m; ++u)
-        for (int64_t e = ev_ptr[u]; e < ev_ptr[u + 1]; ++e) {
-            if (ev_i[e] < 0 || ev_i[e] >= n) return fail(YUE_ERR_ARG, "yue_set_interactions: event item out of range");
-            evu[(size_t)e] = (int32_t)u;
-        }
-    c->E = E; c->nnz = nnz;
-    c->h_ev_ptr.assign(ev_ptr, ev_ptr + m + 1);
-    HIPCHK(c->indptr.resize(m + 1)); HIPCHK(c->indices.resize(std::max<int64_t>(nnz, 1)));
-    HIPCHK(c->ev_u.resize((size_t)E + yue::kHeaderSlack)); HIPCHK(c->ev_i.resize((size_t)E + yue::kHeaderSlack)); HIPCHK(c->ev_j.resize((size_t)E + yue::kHeaderSlack));   // (+ slack: k_round_m reads whole header blocks)
-    HIPCHK(hipMemcpyAsync(c->indptr.p, indptr, (m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->ev_u.p, evu.data(), E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->ev_i.p, ev_i, E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->have_inter = true;
-    return YUE_OK;
-}
 
 int yue_bpr_replay(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
                    double lr, double regU, double regI, double *nll_out) {
     if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_bpr_replay: no factors uploaded");
     if (T < 0 || (T > 0 && (!u || !i || !j))) return fail(YUE_ERR_ARG, "yue_bpr_replay: bad triplet arrays");
     HIPCHK(hipSetDevice(c->device));
+    if (!c->opt_replay_levels) {
+        // default: one dataflow launch (chain_kernels.hpp); ids are checked on the device, the host only copies the stream up
+        int rc = upload_triplets(c, u, i, j, T, false);
+        if (rc) return rc;
+        if ((rc = zero_scalars(c))) return rc;
+        if ((rc = yue_host::chain_stream(c, T, lr, regU, regI))) return rc;
+        return read_scalars(c, nll_out, nullptr, nullptr);
+    }
+    // option replay_levels (the round-1 path, kept for comparison):
     // Dependency levels: a triplet runs one level after the latest earlier triplet that touches
     // P[u], Q[i] or Q[j].  Triplets of a level are pairwise row-disjoint, so running a level
     // concurrently gives exactly the state of the sequential loop (BPR.py:42-58).
@@ -661,11 +413,12 @@ int yue_bpr_replay(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
             pu[(size_t)o] = u[t]; pi[(size_t)o] = i[t]; pj[(size_t)o] = j[t];
         }
     }
-    int rc = upload_triplets(c, pu.data(), pi.data(), pj.data(), Tv);
+    int rc = upload_triplets(c, pu.data(), pi.data(), pj.data(), Tv, true);
     if (rc) return rc;
     yue::TrainArgs a = make_args(c, lr, regU, regI);
     a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
     if ((rc = zero_scalars(c))) return rc;
+    c->replay_levels = nlev;
     for (int32_t l = 1; l <= nlev; ++l) {
         const int64_t e0 = lptr[(size_t)l], e1 = lptr[(size_t)l + 1];
         if (e1 > e0) launch_level(c, a, e0, e1);
@@ -692,7 +445,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
                 if ((int64_t)(hi - lo) * c->k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_bpr_rounds: users of neighbouring triplets are more than 2 GiB of factor rows apart; group the triplets by user");
             }
     }
-    int rc = upload_triplets(c, u, i, j, T);
+    int rc = upload_triplets(c, u, i, j, T, true);
     if (rc) return rc;
     yue::TrainArgs a = make_args(c, lr, regU, regI);
     a.ev_u = c->xu.p; a.ev_i = c->xi.p; a.ev_j = c->xj.p;
@@ -713,7 +466,7 @@ int yue_cune_steps(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
         if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] < 0 || j[t] >= c->n || k[t] >= c->n) return fail(YUE_ERR_ARG, "yue_cune_steps: step " + std::to_string(t) + " out of range");
         if (i[t] == j[t] || k[t] == i[t]) return fail(YUE_ERR_ARG, "yue_cune_steps: step " + std::to_string(t) + ": i must differ from k and from j (k == j is allowed, as in the reference)");
     }
-    int rc = upload_triplets(c, u, i, j, T);
+    int rc = upload_triplets(c, u, i, j, T, true);
     if (rc) return rc;
     HIPCHK(c->xk.resize(T)); HIPCHK(c->x_loss.resize(T));
     HIPCHK(hipMemcpyAsync(c->xk.p, k, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -752,7 +505,7 @@ int yue_adam_step(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t 
     if (c->adam_m != c->m || c->adam_n != c->n || c->adam_k != c->k) { const int rc0 = yue_adam_reset(c); if (rc0) return rc0; }
     for (int64_t t = 0; t < T; ++t)
         if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] < 0 || j[t] >= c->n) return fail(YUE_ERR_ARG, "yue_adam_step: triplet " + std::to_string(t) + " out of range");
-    int rc = upload_triplets(c, u, i, j, T);
+    int rc = upload_triplets(c, u, i, j, T, true);
     if (rc) return rc;
     if ((rc = zero_scalars(c))) return rc;
     yue::MbArgs a{};
@@ -814,6 +567,14 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     const int64_t E = c->E;
     // negatives of the whole epoch in one pass
     if (E > 0) hipLaunchKernelGGL(yue::k_sample, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, c->stream, a, E);
+    if (c->opt_epoch_exact) {
+        // exact sequential semantics over the epoch's triplets (the reference's loop, BPR.py:42-58, on the device sampler's
+        // negatives): one dataflow launch, no rounds.  One GPU only: the order of the whole stream is the semantics.
+        if (c->comm && c->nranks > 1) return fail(YUE_ERR_ARG, "yue_bpr_epoch: option epoch_exact runs on one GPU (the sequential order spans all item shards)");
+        if ((rc = yue_host::chain_epoch(c, lr, regU, regI))) return rc;
+        if ((rc = sumsq_async(c))) return rc;
+        return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
+    }
     // Rounds are blocks of whole users of about round_events events: a user never straddles rounds, so a
     // block's user-row differences are only needed again in the next epoch -- they stay in dP and a group of
     // blocks is applied by k_apply_range.  On a communicator the group is first summed over the ranks, and
@@ -848,7 +609,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         }
         HIPCHK(hipEventRecord(c->ev_rounds, c->stream));
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0));
-        NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream));
+        if (const int rcr = yue_host::reduce_user_block(c, first, count, c->comm_stream)) return rcr;
         hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->comm_stream, c->P.p, c->dP.p, first, count);
         return YUE_OK;
     };
@@ -939,6 +700,13 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "round_bucket") *value = c->opt_round_bucket;
     else if (key == "fold_blocks") *value = c->opt_fold_blocks;
     else if (key == "round_tpw") *value = c->opt_round_tpw;
+    else if (key == "epoch_exact") *value = c->opt_epoch_exact;
+    else if (key == "replay_levels") *value = c->opt_replay_levels;
+    else if (key == "chain_waves") *value = c->opt_chain_waves;
+    else if (key == "chain_spin") *value = c->opt_chain_spin;
+    else if (key == "chain_last_runs") *value = c->chain_runs;          // last exact launch: runs walked, waves launched
+    else if (key == "chain_last_waves") *value = c->chain_waves;
+    else if (key == "replay_last_levels") *value = c->replay_levels;    // last levelled replay: dependency levels = launches
     // which kernels yue_bpr_epoch runs for the uploaded factors: 0 k_round, 1 k_round_meta + k_round_m + k_round_fold
     else if (key == "round_path") *value = fold_path(c) ? 1 : 0;
     else return fail(YUE_ERR_ARG, "yue_get_option: unknown option " + key);
@@ -956,6 +724,10 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
         c->opt_round_stage = (int)value; return YUE_OK;
     }
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
+    if (key == "epoch_exact") { c->opt_epoch_exact = value != 0; return YUE_OK; }
+    if (key == "replay_levels") { c->opt_replay_levels = value != 0; return YUE_OK; }
+    if (key == "chain_waves") { if (value < 0 || value > 8) return fail(YUE_ERR_ARG, "yue_set_option: chain_waves must be 0..8"); c->opt_chain_waves = (int)value; return YUE_OK; }
+    if (key == "chain_spin") { if (value < 0 || value > 0x7fffffff) return fail(YUE_ERR_ARG, "yue_set_option: chain_spin out of range"); c->opt_chain_spin = value; return YUE_OK; }
     if (key == "round_bucket") { c->opt_round_bucket = value != 0; return YUE_OK; }
     if (key == "fold_blocks") { if (value < 1 || value > 65536) return fail(YUE_ERR_ARG, "yue_set_option: fold_blocks out of range"); c->opt_fold_blocks = (int)value; return YUE_OK; }
 #ifdef YUE_STAMPS
@@ -982,315 +754,5 @@ int yue_debug_get_stamps(yue_ctx *c, unsigned long long *out, int64_t max_waves,
     return YUE_OK;
 }
 #endif
-
-int yue_scores(yue_ctx *c, int32_t user, float *out_n) {
-    if (!c || !c->have_factors || !out_n) return fail(YUE_ERR_ARG, "yue_scores: no factors uploaded");
-    if (user < 0 || user >= c->m) return fail(YUE_ERR_ARG, "yue_scores: user id out of range");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(c->s_row.resize(c->n));
-    hipLaunchKernelGGL(yue::k_scores_one, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                       c->P.p + (int64_t)user * c->k, c->Q.p, c->n, c->k, c->s_row.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_n, c->s_row.p, c->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return YUE_OK;
-}
-
-int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int64_t *mask_indptr, const int32_t *mask_indices,
-                  int32_t *out_ids, float *out_scores) {
-    if (!c || !c->have_factors) return fail(YUE_ERR_ARG, "yue_topn_scan: no factors uploaded");
-    if (nu < 0 || (nu > 0 && (!users || !out_ids || !out_scores))) return fail(YUE_ERR_ARG, "yue_topn_scan: null argument");
-    if (N < 1 || N > 100) return fail(YUE_ERR_ARG, "yue_topn_scan: N must be in 1..100");
-    if ((mask_indptr == nullptr) != (mask_indices == nullptr)) return fail(YUE_ERR_ARG, "yue_topn_scan: pass both mask arrays or neither");
-    if (!mask_indptr && !c->have_inter) return fail(YUE_ERR_ARG, "yue_topn_scan: no mask given and no interactions uploaded");
-    if (nu == 0) return YUE_OK;
-    HIPCHK(hipSetDevice(c->device));
-    for (int64_t t = 0; t < nu; ++t) if (users[t] < 0 || users[t] >= c->m) return fail(YUE_ERR_ARG, "yue_topn_scan: user id out of range");
-    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4)); HIPCHK(c->s_work.resize(1));
-    HIPCHK(hipMemcpyAsync(c->s_users.p, users, nu * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    yue::ScanArgs sa{};
-    sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
-    sa.out_ids = c->s_ids.p; sa.out_scores = c->s_scores.p; sa.flags = c->s_flags.p;
-    sa.true_topn = c->opt_topn_true;
-    if (mask_indptr) {
-        const int64_t mnnz = mask_indptr[nu];
-        for (int64_t t = 0; t < nu; ++t) {
-            if (mask_indptr[t + 1] < mask_indptr[t]) return fail(YUE_ERR_ARG, "yue_topn_scan: mask_indptr must be non-decreasing");
-            for (int64_t q = mask_indptr[t]; q < mask_indptr[t + 1]; ++q)
-                if (mask_indices[q] < 0 || mask_indices[q] >= c->n || (q > mask_indptr[t] && mask_indices[q] <= mask_indices[q - 1]))
-                    return fail(YUE_ERR_ARG, "yue_topn_scan: mask rows must be sorted, unique and in range");
-        }
-        HIPCHK(c->s_mask_ptr.resize(nu + 1)); HIPCHK(c->s_mask_idx.resize(std::max<int64_t>(mnnz, 1)));
-        HIPCHK(hipMemcpyAsync(c->s_mask_ptr.p, mask_indptr, (nu + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->s_mask_idx.p, mask_indices, mnnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        sa.mask_ptr = c->s_mask_ptr.p; sa.mask_idx = c->s_mask_idx.p; sa.mask_by_user = 0;
-    } else {
-        sa.mask_ptr = c->indptr.p; sa.mask_idx = c->indices.p; sa.mask_by_user = 1;
-    }
-    HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->s_work.p, 0, sizeof(unsigned long long), c->stream));
-    sa.work = c->s_work.p;
-    const int64_t ntile = (c->n + 31) / 32;
-    HIPCHK(c->s_norms.resize(2 * ntile));
-    hipLaunchKernelGGL(yue::k_tile_norm_max, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, c->stream, c->Q.p, c->n, c->k, c->s_norms.p);
-    hipLaunchKernelGGL(yue::k_tile_norm_sufmax, dim3(1), dim3(64), 0, c->stream, c->s_norms.p, ntile, c->s_norms.p + ntile);
-    sa.tile_norm_max = c->s_norms.p;
-    sa.tile_norm_sufmax = c->s_norms.p + ntile;
-    const hipEvent_t t0 = c->ev_scan0, t1 = c->ev_scan1;
-    HIPCHK(hipEventRecord(t0, c->stream));
-    int rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32, c->opt_scan_batch);
-    HIPCHK(hipEventRecord(t1, c->stream));
-    if (rc < 0) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination (k <= 256; for k > 128 the list length N is limited to 66)");
-    c->scan_used_bf16 = rc;
-    HIPCHK(hipGetLastError());
-    int32_t flags[4];
-    HIPCHK(hipMemcpyAsync(out_ids, c->s_ids.p, nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(out_scores, c->s_scores.p, nu * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(flags, c->s_flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
-    unsigned long long work = 0;
-    HIPCHK(hipMemcpyAsync(&work, c->s_work.p, sizeof work, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, t0, t1));
-    c->scan_ms = ms;
-    c->scan_events = flags[1];
-    c->scan_rescored = flags[2];
-    c->scan_tiles_done = (int64_t)work;
-    c->scan_tiles_total = ((nu + 31) / 32) * ntile;
-    if (flags[0]) return fail(YUE_ERR_FEW_ITEMS, "a user has fewer than N candidate items (the reference raises IndexError, base/IterativeRecommender.py:126)");
-    return YUE_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// FISM (recommender/cf/FISM.py), parity path
-// ---------------------------------------------------------------------------------------------
-int yue_fism_set_model(yue_ctx *c, const double *P, const float *Q, const double *Bi, int64_t n, int k) {
-    if (!c || !P || !Q || !Bi) return fail(YUE_ERR_ARG, "yue_fism_set_model: null argument");
-    if (n <= 0 || k <= 0 || k > 256 || n >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_fism_set_model: need 0 < n < 2^31 and 1 <= k <= 256");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(c->fP.resize((size_t)n * k)); HIPCHK(c->fQ.resize((size_t)n * k)); HIPCHK(c->fBi.resize((size_t)n));
-    HIPCHK(hipMemcpyAsync(c->fP.p, P, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->fQ.p, Q, (size_t)n * k * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->fBi.p, Bi, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->fn = n; c->fk = k;
-    return YUE_OK;
-}
-
-int yue_fism_get_model(yue_ctx *c, double *P, float *Q, double *Bi) {
-    if (!c || c->fn == 0) return fail(YUE_ERR_ARG, "yue_fism_get_model: no FISM model uploaded");
-    HIPCHK(hipSetDevice(c->device));
-    if (P) HIPCHK(hipMemcpyAsync(P, c->fP.p, (size_t)c->fn * c->fk * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (Q) HIPCHK(hipMemcpyAsync(Q, c->fQ.p, (size_t)c->fn * c->fk * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (Bi) HIPCHK(hipMemcpyAsync(Bi, c->fBi.p, (size_t)c->fn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return YUE_OK;
-}
-
-namespace {
-// uploads a CSR of item rows (user_ptr[rows+1], items) after checking it
-int fism_upload_rows(yue_ctx *c, const int64_t *ptr, int64_t rows, const int32_t *items, const char *who) {
-    if (rows < 0 || !ptr || ptr[0] != 0) return fail(YUE_ERR_ARG, std::string(who) + ": bad row pointer");
-    for (int64_t r = 0; r < rows; ++r) if (ptr[r + 1] < ptr[r]) return fail(YUE_ERR_ARG, std::string(who) + ": row pointer must be non-decreasing");
-    const int64_t E = ptr[rows];
-    if (E > 0 && !items) return fail(YUE_ERR_ARG, std::string(who) + ": null items");
-    for (int64_t e = 0; e < E; ++e) if (items[e] < 0 || items[e] >= c->fn) return fail(YUE_ERR_ARG, std::string(who) + ": item id out of range");
-    HIPCHK(c->f_ptr.resize((size_t)rows + 1)); HIPCHK(c->f_items.resize((size_t)std::max<int64_t>(E, 1)));
-    HIPCHK(hipMemcpyAsync(c->f_ptr.p, ptr, ((size_t)rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    if (E > 0) HIPCHK(hipMemcpyAsync(c->f_items.p, items, (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    return YUE_OK;
-}
-}  // namespace
-
-int yue_fism_epoch(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_t *ev_i, const int32_t *negs, int64_t n_negs, int rho,
-                   const double *coef, double lr, double regI, double regB, double *half_sq_out, double *sumsq3_out) {
-    if (!c || c->fn == 0) return fail(YUE_ERR_ARG, "yue_fism_epoch: no FISM model uploaded");
-    if (m <= 0 || rho < 1 || !coef || (n_negs > 0 && !negs)) return fail(YUE_ERR_ARG, "yue_fism_epoch: bad argument");
-    HIPCHK(hipSetDevice(c->device));
-    int rc = fism_upload_rows(c, user_ptr, m, ev_i, "yue_fism_epoch");
-    if (rc) return rc;
-    int64_t need = 0, widest = 1;
-    for (int64_t u = 0; u < m; ++u) { const int64_t nu = user_ptr[u + 1] - user_ptr[u]; if (nu > 1) need += nu * rho; widest = std::max(widest, nu); }
-    if (need != n_negs) return fail(YUE_ERR_ARG, "yue_fism_epoch: need rho negatives per event of every user with more than one event (" + std::to_string(need) + "), got " + std::to_string(n_negs));
-    for (int64_t t = 0; t < n_negs; ++t) if (negs[t] < 0 || negs[t] >= c->fn) return fail(YUE_ERR_ARG, "yue_fism_epoch: negative item id out of range");
-    HIPCHK(c->f_negs.resize((size_t)std::max<int64_t>(n_negs, 1))); HIPCHK(c->f_coef.resize((size_t)m)); HIPCHK(c->f_x.resize((size_t)widest * c->fk));
-    if (n_negs > 0) HIPCHK(hipMemcpyAsync(c->f_negs.p, negs, (size_t)n_negs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->f_coef.p, coef, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    double *sc = c->scal.p + yue::kNllSlots;              // [0] half_sq, [1..3] sums of squares
-    HIPCHK(hipMemsetAsync(sc, 0, 4 * sizeof(double), c->stream));
-    yue::FismArgs a{};
-    a.P = c->fP.p; a.Q = c->fQ.p; a.Bi = c->fBi.p; a.n = c->fn; a.k = c->fk;
-    a.user_ptr = c->f_ptr.p; a.m = m; a.ev_i = c->f_items.p; a.negs = c->f_negs.p; a.rho = rho; a.coef = c->f_coef.p;
-    a.lr = lr; a.regI = regI; a.regB = regB; a.x_rows = c->f_x.p; a.out = sc;
-    switch (kr_of(c->fk)) {
-        case 1: hipLaunchKernelGGL(yue::k_fism_epoch<1>, dim3(1), dim3(64), 0, c->stream, a); break;
-        case 2: hipLaunchKernelGGL(yue::k_fism_epoch<2>, dim3(1), dim3(64), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(yue::k_fism_epoch<4>, dim3(1), dim3(64), 0, c->stream, a); break;
-    }
-    hipLaunchKernelGGL(yue::k_fism_sumsq, dim3(256), dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, sc + 1);
-    HIPCHK(hipGetLastError());
-    double h[4];
-    HIPCHK(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (half_sq_out) *half_sq_out = h[0];
-    if (sumsq3_out) { sumsq3_out[0] = h[1]; sumsq3_out[1] = h[2]; sumsq3_out[2] = h[3]; }
-    return YUE_OK;
-}
-
-int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_t *ev_i, const int32_t *negs, int64_t n_negs, int rho,
-                    const double *coef, int64_t round_users, double lr, double regI, double regB, double *half_sq_out, double *sumsq3_out) {
-    if (!c || c->fn == 0) return fail(YUE_ERR_ARG, "yue_fism_rounds: no FISM model uploaded");
-    if (m <= 0 || rho < 1 || round_users < 1 || !coef || (n_negs > 0 && !negs)) return fail(YUE_ERR_ARG, "yue_fism_rounds: bad argument");
-    HIPCHK(hipSetDevice(c->device));
-    int rc = fism_upload_rows(c, user_ptr, m, ev_i, "yue_fism_rounds");
-    if (rc) return rc;
-    const int64_t E = user_ptr[m];
-    // per user: first draw, the sorted unique list of the items it touches, and every event's / draw's position in it
-    std::vector<int64_t> neg_ptr((size_t)m + 1, 0), uq_ptr((size_t)m + 1, 0);
-    for (int64_t u = 0; u < m; ++u) { const int64_t nu = user_ptr[u + 1] - user_ptr[u]; neg_ptr[(size_t)u + 1] = neg_ptr[(size_t)u] + (nu > 1 ? nu * rho : 0); }
-    if (neg_ptr[(size_t)m] != n_negs) return fail(YUE_ERR_ARG, "yue_fism_rounds: need rho negatives per event of every user with more than one event (" + std::to_string(neg_ptr[(size_t)m]) + "), got " + std::to_string(n_negs));
-    for (int64_t t = 0; t < n_negs; ++t) if (negs[t] < 0 || negs[t] >= c->fn) return fail(YUE_ERR_ARG, "yue_fism_rounds: negative item id out of range");
-    std::vector<int32_t> uq_items, loc_i((size_t)std::max<int64_t>(E, 1)), loc_j((size_t)std::max<int64_t>(n_negs, 1)), tmp;
-    for (int64_t u = 0; u < m; ++u) {
-        tmp.assign(ev_i + user_ptr[u], ev_i + user_ptr[u + 1]);
-        tmp.insert(tmp.end(), negs + neg_ptr[(size_t)u], negs + neg_ptr[(size_t)u + 1]);
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        for (int64_t e = user_ptr[u]; e < user_ptr[u + 1]; ++e) loc_i[(size_t)e] = (int32_t)(std::lower_bound(tmp.begin(), tmp.end(), ev_i[e]) - tmp.begin());
-        for (int64_t t = neg_ptr[(size_t)u]; t < neg_ptr[(size_t)u + 1]; ++t) loc_j[(size_t)t] = (int32_t)(std::lower_bound(tmp.begin(), tmp.end(), negs[t]) - tmp.begin());
-        uq_items.insert(uq_items.end(), tmp.begin(), tmp.end());
-        uq_ptr[(size_t)u + 1] = (int64_t)uq_items.size();
-    }
-    int64_t rows_max = 1, ev_max = 1;                          // working rows / events of the largest round
-    for (int64_t u0 = 0; u0 < m; u0 += round_users) {
-        const int64_t u1 = std::min(m, u0 + round_users);
-        rows_max = std::max(rows_max, uq_ptr[(size_t)u1] - uq_ptr[(size_t)u0]);
-        ev_max = std::max(ev_max, user_ptr[u1] - user_ptr[u0]);
-    }
-    const size_t nk = (size_t)c->fn * c->fk;
-    HIPCHK(c->f_uq_ptr.resize((size_t)m + 1)); HIPCHK(c->f_neg_ptr.resize((size_t)m + 1)); HIPCHK(c->f_uq_items.resize(std::max<size_t>(uq_items.size(), 1)));
-    HIPCHK(c->f_loc_i.resize(loc_i.size())); HIPCHK(c->f_loc_j.resize(loc_j.size())); HIPCHK(c->f_coef.resize((size_t)m));
-    HIPCHK(c->f_wq.resize((size_t)rows_max * c->fk)); HIPCHK(c->f_wp.resize((size_t)rows_max * c->fk)); HIPCHK(c->f_wb.resize((size_t)rows_max));
-    HIPCHK(c->f_x.resize((size_t)ev_max * c->fk));
-    HIPCHK(c->f_dQ.resize(nk)); HIPCHK(c->f_dP.resize(nk)); HIPCHK(c->f_dB.resize((size_t)c->fn));
-    HIPCHK(hipMemcpyAsync(c->f_uq_ptr.p, uq_ptr.data(), ((size_t)m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->f_neg_ptr.p, neg_ptr.data(), ((size_t)m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    if (!uq_items.empty()) HIPCHK(hipMemcpyAsync(c->f_uq_items.p, uq_items.data(), uq_items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    if (E > 0) HIPCHK(hipMemcpyAsync(c->f_loc_i.p, loc_i.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    if (n_negs > 0) HIPCHK(hipMemcpyAsync(c->f_loc_j.p, loc_j.data(), (size_t)n_negs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->f_coef.p, coef, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->f_dQ.p, 0, nk * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(c->f_dP.p, 0, nk * sizeof(double), c->stream));
-    HIPCHK(hipMemsetAsync(c->f_dB.p, 0, (size_t)c->fn * sizeof(double), c->stream));
-    double *sc = c->scal.p + yue::kNllSlots;              // [0] half_sq, [1..3] sums of squares
-    HIPCHK(hipMemsetAsync(sc, 0, 4 * sizeof(double), c->stream));
-    yue::FismArgs a{};
-    a.P = c->fP.p; a.Q = c->fQ.p; a.Bi = c->fBi.p; a.n = c->fn; a.k = c->fk;
-    a.user_ptr = c->f_ptr.p; a.m = m; a.ev_i = c->f_items.p; a.negs = nullptr; a.rho = rho; a.coef = c->f_coef.p;
-    a.lr = lr; a.regI = regI; a.regB = regB; a.x_rows = c->f_x.p; a.out = sc;
-    yue::FismRoundArgs ra{};
-    ra.uq_ptr = c->f_uq_ptr.p; ra.uq_items = c->f_uq_items.p; ra.loc_i = c->f_loc_i.p; ra.loc_j = c->f_loc_j.p; ra.neg_ptr = c->f_neg_ptr.p;
-    ra.wq = c->f_wq.p; ra.wp = c->f_wp.p; ra.wb = c->f_wb.p; ra.dQ = c->f_dQ.p; ra.dP = c->f_dP.p; ra.dB = c->f_dB.p;
-    const dim3 apply_grid((unsigned)std::min<int64_t>(1024, (int64_t)(nk + 255) / 256));
-    for (int64_t u0 = 0; u0 < m; u0 += round_users) {
-        const int64_t u1 = std::min(m, u0 + round_users);
-        ra.u_begin = u0; ra.u_end = u1; ra.w_base = uq_ptr[(size_t)u0];
-        const dim3 grid((unsigned)((u1 - u0 + 3) / 4));
-        switch (kr_of(c->fk)) {
-            case 1: hipLaunchKernelGGL(yue::k_fism_round<1>, grid, dim3(256), 0, c->stream, a, ra); break;
-            case 2: hipLaunchKernelGGL(yue::k_fism_round<2>, grid, dim3(256), 0, c->stream, a, ra); break;
-            default: hipLaunchKernelGGL(yue::k_fism_round<4>, grid, dim3(256), 0, c->stream, a, ra); break;
-        }
-        hipLaunchKernelGGL(yue::k_fism_apply, apply_grid, dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->f_dP.p, c->f_dQ.p, c->f_dB.p, c->fn, c->fk);
-    }
-    hipLaunchKernelGGL(yue::k_fism_sumsq, dim3(256), dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, sc + 1);
-    HIPCHK(hipGetLastError());
-    double h[4];
-    HIPCHK(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (half_sq_out) *half_sq_out = h[0];
-    if (sumsq3_out) { sumsq3_out[0] = h[1]; sumsq3_out[1] = h[2]; sumsq3_out[2] = h[3]; }
-    return YUE_OK;
-}
-
-namespace {
-// scores[nu][n] of the users whose training rows were uploaded with fism_upload_rows
-int fism_score_rows(yue_ctx *c, int64_t nu) {
-    HIPCHK(c->f_hist.resize((size_t)nu * c->fk)); HIPCHK(c->f_scores.resize((size_t)nu * c->fn));
-    hipLaunchKernelGGL(yue::k_fism_hist, dim3((unsigned)nu), dim3(256), 0, c->stream, c->fP.p, c->fk, c->f_ptr.p, c->f_items.p, c->f_hist.p);
-    const int64_t tot = nu * c->fn;
-    hipLaunchKernelGGL(yue::k_fism_scores, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                       c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, c->f_hist.p, nu, c->f_scores.p);
-    HIPCHK(hipGetLastError());
-    return YUE_OK;
-}
-}  // namespace
-
-int yue_fism_scores(yue_ctx *c, const int32_t *items, int64_t n_items, double *out_n) {
-    if (!c || c->fn == 0 || !out_n) return fail(YUE_ERR_ARG, "yue_fism_scores: no FISM model uploaded");
-    HIPCHK(hipSetDevice(c->device));
-    const int64_t ptr[2] = {0, n_items};
-    int rc = fism_upload_rows(c, ptr, 1, items, "yue_fism_scores");
-    if (rc) return rc;
-    if ((rc = fism_score_rows(c, 1))) return rc;
-    HIPCHK(hipMemcpyAsync(out_n, c->f_scores.p, (size_t)c->fn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return YUE_OK;
-}
-
-int yue_fism_topn_scan(yue_ctx *c, const int64_t *row_ptr, const int32_t *row_items, int64_t nu, int N, int32_t *out_ids, double *out_scores) {
-    if (!c || c->fn == 0) return fail(YUE_ERR_ARG, "yue_fism_topn_scan: no FISM model uploaded");
-    if (nu < 0 || (nu > 0 && (!out_ids || !out_scores))) return fail(YUE_ERR_ARG, "yue_fism_topn_scan: null argument");
-    if (N < 1 || N > 100) return fail(YUE_ERR_ARG, "yue_fism_topn_scan: N must be in 1..100");
-    if (nu == 0) return YUE_OK;
-    if (nu * c->fn >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_fism_topn_scan: users x items of one call must stay below 2^31 (call in chunks)");
-    HIPCHK(hipSetDevice(c->device));
-    int rc = fism_upload_rows(c, row_ptr, nu, row_items, "yue_fism_topn_scan");
-    if (rc) return rc;
-    if ((rc = fism_score_rows(c, nu))) return rc;
-    HIPCHK(c->f_ids.resize((size_t)nu * N)); HIPCHK(c->f_out_sc.resize((size_t)nu * N)); HIPCHK(c->f_flags.resize((size_t)nu));
-    hipLaunchKernelGGL(yue::k_fism_select, dim3((unsigned)((nu + 63) / 64)), dim3(64), 0, c->stream, c->f_scores.p, c->fn, nu, N,
-                       c->f_ptr.p, c->f_items.p, c->f_ids.p, c->f_out_sc.p, c->f_flags.p);
-    HIPCHK(hipGetLastError());
-    std::vector<int32_t> flags((size_t)nu);
-    HIPCHK(hipMemcpyAsync(out_ids, c->f_ids.p, (size_t)nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(out_scores, c->f_out_sc.p, (size_t)nu * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(flags.data(), c->f_flags.p, (size_t)nu * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int64_t t = 0; t < nu; ++t) if (flags[(size_t)t]) return fail(YUE_ERR_FEW_ITEMS, "yue_fism_topn_scan: user at position " + std::to_string(t) + " has fewer than N candidates");
-    return YUE_OK;
-}
-
-int yue_comm_unique_id(void *id128_out) {
-    if (!id128_out) return fail(YUE_ERR_ARG, "yue_comm_unique_id: null argument");
-    static_assert(sizeof(ncclUniqueId) <= YUE_UNIQUE_ID_BYTES, "ncclUniqueId larger than the ABI slot");
-    ncclUniqueId id;
-    NCCLCHK(ncclGetUniqueId(&id));
-    std::memset(id128_out, 0, YUE_UNIQUE_ID_BYTES);
-    std::memcpy(id128_out, &id, sizeof id);
-    return YUE_OK;
-}
-
-int yue_comm_init(yue_ctx *c, const void *id128, int rank, int nranks) {
-    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(YUE_ERR_ARG, "yue_comm_init: bad argument");
-    HIPCHK(hipSetDevice(c->device));
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof id);
-    NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
-    c->rank = rank; c->nranks = nranks;
-    return YUE_OK;
-}
-
-int yue_allreduce_f64(yue_ctx *c, double *vals, int count) {
-    if (!c || !vals || count < 1 || count > 8) return fail(YUE_ERR_ARG, "yue_allreduce_f64: bad argument (count 1..8)");
-    if (!c->comm) return YUE_OK;
-    HIPCHK(hipSetDevice(c->device));
-    double *d = c->scal.p + yue::kNllSlots;   // scratch scalars (callers read their results before)
-    HIPCHK(hipMemcpyAsync(d, vals, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
-    HIPCHK(hipMemcpyAsync(vals, d, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return YUE_OK;
-}
 
 }  // extern "C"

@@ -1,0 +1,142 @@
+// libyue_hip.so -- exact sequential semantics of recommender/cf/BPR.py:40-62 as a dataflow launch (chain_kernels.hpp):
+// yue_bpr_replay on any triplet stream, and yue_bpr_epoch's exact mode on the uploaded events (option "epoch_exact").
+// Everything that scales with the number of triplets runs on the device: the row ordinals come from a stable radix sort
+// of the touches by row (rocPRIM, the ROCm primitives library -- a pre-pass, not the hot loop), run boundaries from a
+// prefix sum.  The host issues launches and copies the stream up once.
+#include "host_common.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include "chain_kernels.hpp"
+
+using yue_host::fail;
+using yue_host::kr_of;
+
+namespace {
+
+int bits_for(uint64_t values) { int b = 1; while ((1ull << b) < values) ++b; return b; }
+
+// ord[code] = number of earlier entries with the same key (stable sort by key, position minus segment start).
+// key / val hold `count` entries (clobbered); keys are < nkeys, or == nkeys for entries to ignore.
+int rank_in_stream(yue_ctx *c, DevBuf<uint32_t> &key, DevBuf<uint32_t> &val, int64_t count, uint32_t nkeys, uint32_t *ord_a, uint32_t *ord_b) {
+    if (count == 0) return YUE_OK;
+    HIPCHK(c->ch_key2.resize((size_t)count)); HIPCHK(c->ch_val2.resize((size_t)count)); HIPCHK(c->ch_seg.resize((size_t)nkeys + 1));
+    rocprim::double_buffer<uint32_t> dk(key.p, c->ch_key2.p), dv(val.p, c->ch_val2.p);
+    size_t tmp = 0;
+    const unsigned end_bit = (unsigned)bits_for((uint64_t)nkeys + 1);
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, (size_t)count, 0u, end_bit, c->stream));
+    HIPCHK(c->ch_tmp.resize(tmp + 16));
+    HIPCHK(rocprim::radix_sort_pairs(c->ch_tmp.p, tmp, dk, dv, (size_t)count, 0u, end_bit, c->stream));
+    const dim3 grid((unsigned)((count + 255) / 256));
+    hipLaunchKernelGGL(yue::k_chain_seg, grid, dim3(256), 0, c->stream, dk.current(), count, nkeys, c->ch_seg.p);
+    hipLaunchKernelGGL(yue::k_chain_ord, grid, dim3(256), 0, c->stream, dk.current(), dv.current(), count, nkeys, c->ch_seg.p, ord_a, ord_b);
+    HIPCHK(hipGetLastError());
+    return YUE_OK;
+}
+
+// Runs the dataflow launch over the triplets (ev_i, ev_j)[T] grouped into R runs.  ev_u / run_u null: run r is user r.
+int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int32_t *ev_j, int64_t T, const int64_t *run_ptr, const int32_t *run_u,
+                 const uint32_t *ord_u, int64_t R, double lr, double regU, double regI) {
+    const int64_t n = c->n, m = c->m;
+    const int k = c->k;
+    if (n * (int64_t)k * 8 >= (1ll << 31)) return fail(YUE_ERR_ARG, "exact path: the granule copy of the item matrix must stay below 2 GiB (n*k*8 < 2^31)");
+    if (2 * T >= (1ll << 32)) return fail(YUE_ERR_ARG, "exact path: at most 2^31 - 1 triplets per call");
+    HIPCHK(c->ch_key.resize((size_t)(2 * T))); HIPCHK(c->ch_val.resize((size_t)(2 * T)));
+    HIPCHK(c->ch_ord_i.resize((size_t)T)); HIPCHK(c->ch_ord_j.resize((size_t)T));
+    HIPCHK(c->ch_ctl.resize(4));
+    HIPCHK(hipMemsetAsync(c->ch_ctl.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    uint32_t *flags = reinterpret_cast<uint32_t *>(c->ch_ctl.p + 1), *status = reinterpret_cast<uint32_t *>(c->ch_ctl.p + 2);
+    const dim3 tgrid((unsigned)((T + 255) / 256));
+    hipLaunchKernelGGL(yue::k_chain_keys, tgrid, dim3(256), 0, c->stream, ev_u, ev_i, ev_j, T, m, (uint32_t)n, c->ch_key.p, c->ch_val.p, flags);
+    int rc = rank_in_stream(c, c->ch_key, c->ch_val, 2 * T, (uint32_t)n, c->ch_ord_i.p, c->ch_ord_j.p);
+    if (rc) return rc;
+    {   // ids are checked on the device; nothing has been written to the factors yet
+        unsigned long long fl = 0;
+        HIPCHK(hipMemcpyAsync(&fl, c->ch_ctl.p + 1, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (fl & 1u) return fail(YUE_ERR_ARG, "a triplet's user or item id is out of range");
+        if (fl & 2u) return fail(YUE_ERR_ARG, "a triplet has i == j");
+    }
+    // item rows -> granules (and the user rows, when a user may have several runs)
+    const size_t nk = (size_t)n * k, mk = (size_t)m * k;
+    HIPCHK(c->ch_Qv.resize(nk));
+    hipLaunchKernelGGL(yue::k_chain_pack, dim3(2048), dim3(256), 0, c->stream, c->Q.p, reinterpret_cast<yue::u32x2 *>(c->ch_Qv.p), (int64_t)nk);
+    if (ord_u) {
+        HIPCHK(c->ch_Pv.resize(mk));
+        hipLaunchKernelGGL(yue::k_chain_pack, dim3(2048), dim3(256), 0, c->stream, c->P.p, reinterpret_cast<yue::u32x2 *>(c->ch_Pv.p), (int64_t)mk);
+    }
+    yue::ChainArgs a{};
+    a.P = c->P.p; a.Pv = ord_u ? reinterpret_cast<yue::u32x2 *>(c->ch_Pv.p) : nullptr; a.Qv = reinterpret_cast<yue::u32x2 *>(c->ch_Qv.p);
+    a.run_ptr = run_ptr; a.run_u = run_u; a.ord_u = ord_u; a.ev_i = ev_i; a.ev_j = ev_j; a.ord_i = c->ch_ord_i.p; a.ord_j = c->ch_ord_j.p;
+    a.R = R; a.claim = c->ch_ctl.p; a.status = status; a.nll_slots = c->scal.p; a.m = m; a.n = n; a.k = k;
+    a.ru = (float)(lr * regU); a.ri = (float)(lr * regI); a.lr = lr;          // BPR.py:55: python-float product, cast to fp32 by NumPy
+    a.spin_limit = c->opt_chain_spin > 0 ? (uint32_t)c->opt_chain_spin : (1u << 22);
+    // one persistent launch: exactly the waves the chip holds at once (a wave that is not resident cannot be waited for)
+    int per_cu = 0, cus = 0;
+    const int kr = kr_of(k);
+#define YUE_CHAIN(KR_, PV_) \
+    do { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain<KR_, PV_>, 256, 0)); } while (0)
+    if (ord_u) { if (kr == 1) YUE_CHAIN(1, true); else if (kr == 2) YUE_CHAIN(2, true); else YUE_CHAIN(4, true); }
+    else { if (kr == 1) YUE_CHAIN(1, false); else if (kr == 2) YUE_CHAIN(2, false); else YUE_CHAIN(4, false); }
+#undef YUE_CHAIN
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 8));
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 3) / 4));
+    const dim3 grid((unsigned)blocks), block(256);
+#define YUE_CHAIN(KR_, PV_) hipLaunchKernelGGL((yue::k_bpr_chain<KR_, PV_>), grid, block, 0, c->stream, a)
+    if (ord_u) { if (kr == 1) YUE_CHAIN(1, true); else if (kr == 2) YUE_CHAIN(2, true); else YUE_CHAIN(4, true); }
+    else { if (kr == 1) YUE_CHAIN(1, false); else if (kr == 2) YUE_CHAIN(2, false); else YUE_CHAIN(4, false); }
+#undef YUE_CHAIN
+    hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, reinterpret_cast<const yue::u32x2 *>(c->ch_Qv.p), c->Q.p, (int64_t)nk);
+    if (ord_u) hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, reinterpret_cast<const yue::u32x2 *>(c->ch_Pv.p), c->P.p, (int64_t)mk);
+    HIPCHK(hipGetLastError());
+    unsigned long long ctl[4];
+    HIPCHK(hipMemcpyAsync(ctl, c->ch_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t st = (uint32_t)ctl[2];
+    c->chain_runs = R; c->chain_waves = blocks * 4;
+    if (st) return fail(YUE_ERR_HIP, std::string("exact path: a wave gave up waiting for a row (") + ((st & 2u) ? "a row's version ran past a waiting touch" : "spin limit") +
+                                    "): internal error, the factors on the device are not usable");
+    return YUE_OK;
+}
+
+}  // namespace
+
+namespace yue_host {
+
+// The uploaded events (user-major, the sampler's negatives in ev_j) with exact sequential semantics: a run = a user.
+int chain_epoch(yue_ctx *c, double lr, double regU, double regI) {
+    if (c->E == 0) return YUE_OK;
+    HIPCHK(c->d_ev_ptr.resize((size_t)c->m + 1));
+    if (!c->d_ev_ptr_valid) {
+        HIPCHK(hipMemcpyAsync(c->d_ev_ptr.p, c->h_ev_ptr.data(), ((size_t)c->m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        c->d_ev_ptr_valid = true;
+    }
+    return chain_launch(c, nullptr, c->ev_i.p, c->ev_j.p, c->E, c->d_ev_ptr.p, nullptr, nullptr, c->m, lr, regU, regI);
+}
+
+// Any triplet stream on the device (xu, xi, xj): runs of equal consecutive users, user rows versioned per run.
+int chain_stream(yue_ctx *c, int64_t T, double lr, double regU, double regI) {
+    if (T == 0) return YUE_OK;
+    if (T >= (1ll << 31)) return fail(YUE_ERR_ARG, "exact path: at most 2^31 - 1 triplets per call");
+    HIPCHK(c->ch_head.resize((size_t)T)); HIPCHK(c->ch_incl.resize((size_t)T));
+    const dim3 tgrid((unsigned)((T + 255) / 256));
+    hipLaunchKernelGGL(yue::k_chain_heads, tgrid, dim3(256), 0, c->stream, c->xu.p, T, c->ch_head.p);
+    size_t tmp = 0;
+    HIPCHK(rocprim::inclusive_scan(nullptr, tmp, c->ch_head.p, c->ch_incl.p, (size_t)T, rocprim::plus<uint32_t>(), c->stream));
+    HIPCHK(c->ch_tmp.resize(tmp + 16));
+    HIPCHK(rocprim::inclusive_scan(c->ch_tmp.p, tmp, c->ch_head.p, c->ch_incl.p, (size_t)T, rocprim::plus<uint32_t>(), c->stream));
+    uint32_t R32 = 0;
+    HIPCHK(hipMemcpyAsync(&R32, c->ch_incl.p + (T - 1), sizeof R32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int64_t R = R32;
+    HIPCHK(c->ch_run_ptr.resize((size_t)R + 1)); HIPCHK(c->ch_run_u.resize((size_t)R)); HIPCHK(c->ch_ord_u.resize((size_t)R));
+    HIPCHK(c->ch_rkey.resize((size_t)R)); HIPCHK(c->ch_rval.resize((size_t)R));
+    hipLaunchKernelGGL(yue::k_chain_runs, tgrid, dim3(256), 0, c->stream, c->xu.p, c->ch_head.p, c->ch_incl.p, T, c->ch_run_ptr.p, c->ch_run_u.p, c->ch_rkey.p, c->ch_rval.p, (uint32_t)c->m);
+    // (user ids out of range sort behind all users here and are reported by k_chain_keys before anything is written)
+    int rc = rank_in_stream(c, c->ch_rkey, c->ch_rval, R, (uint32_t)c->m, c->ch_ord_u.p, nullptr);
+    if (rc) return rc;
+    return chain_launch(c, c->xu.p, c->xi.p, c->xj.p, T, c->ch_run_ptr.p, c->ch_run_u.p, c->ch_ord_u.p, R, lr, regU, regI);
+}
+
+}  // namespace yue_host

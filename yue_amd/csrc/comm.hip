@@ -1,0 +1,62 @@
+// libyue_hip.so -- RCCL over xGMI: communicator set-up and the two collectives of the path (include/yue_hip.h).
+#include "host_common.hpp"
+
+#include <rccl/rccl.h>
+
+using yue_host::fail;
+
+#define NCCLCHK(expr)                                                                             \
+    do {                                                                                          \
+        ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail(YUE_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));        \
+    } while (0)
+
+void yue_comm_release(yue_ctx *c) { if (c->comm) (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+
+namespace yue_host {
+// The one data-path collective: the user-factor differences of a group of user blocks, summed over the item
+// shards.  In place, fp32, on the given stream (yue_bpr_epoch passes its second stream, event-ordered behind the rounds).
+int reduce_user_block(yue_ctx *c, int64_t first, int64_t count, hipStream_t stream) {
+    if (!c->comm) return YUE_OK;
+    NCCLCHK(ncclAllReduce(c->dP.p + first, c->dP.p + first, (size_t)count, ncclFloat, ncclSum, c->comm, stream));
+    return YUE_OK;
+}
+}  // namespace yue_host
+
+extern "C" {
+
+
+int yue_comm_unique_id(void *id128_out) {
+    if (!id128_out) return fail(YUE_ERR_ARG, "yue_comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) <= YUE_UNIQUE_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    std::memset(id128_out, 0, YUE_UNIQUE_ID_BYTES);
+    std::memcpy(id128_out, &id, sizeof id);
+    return YUE_OK;
+}
+
+int yue_comm_init(yue_ctx *c, const void *id128, int rank, int nranks) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(YUE_ERR_ARG, "yue_comm_init: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->rank = rank; c->nranks = nranks;
+    return YUE_OK;
+}
+
+int yue_allreduce_f64(yue_ctx *c, double *vals, int count) {
+    if (!c || !vals || count < 1 || count > 8) return fail(YUE_ERR_ARG, "yue_allreduce_f64: bad argument (count 1..8)");
+    if (!c->comm) return YUE_OK;
+    HIPCHK(hipSetDevice(c->device));
+    double *d = c->scal.p + yue_host::kNllSlotsHost;   // scratch scalars (callers read their results before)
+    HIPCHK(hipMemcpyAsync(d, vals, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, d, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return YUE_OK;
+}
+
+}  // extern "C"

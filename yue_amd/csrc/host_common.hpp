@@ -1,0 +1,154 @@
+// Host side of libyue_hip.so, shared by its translation units: the opaque context (device buffers, streams, options),
+// error plumbing, and the few helpers more than one subsystem uses.  The C ABI is include/yue_hip.h.
+//   core_host.hip   context, factors, interactions            bpr_host.hip   replay levels, S-rounds, epochs, CUNE, Adam, options
+//   chain_host.hip  exact sequential semantics as dataflow    scan_host.hip  predict + evalRanking's selection
+//   fism_host.hip   FISM                                      comm.hip       RCCL
+#pragma once
+#include "../../include/yue_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct ncclComm;
+
+namespace yue_host {
+
+int fail(int code, const std::string &msg);          // sets the thread-local message of yue_last_error(), returns code
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return yue_host::fail(YUE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; n = 0; if (e != hipSuccess) return e; }
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+constexpr int kNllSlotsHost = 1024;   // == yue::kNllSlots (bpr_device.hpp; checked where both are visible)
+constexpr int kHeaderSlackHost = 16;  // == yue::kHeaderSlack (round_kernels.hpp)
+
+inline int kr_of(int k) { return k <= 64 ? 1 : k <= 128 ? 2 : 4; }   // registers per lane per row (64 lanes)
+
+}  // namespace yue_host
+
+using yue_host::DevBuf;
+
+struct yue_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t m = 0, n = 0, E = 0, nnz = 0;
+    int k = 0;
+    bool have_factors = false, have_inter = false;
+    DevBuf<float> P, Q, dP, dQ;
+    DevBuf<unsigned long long> cnt0, cnt1;       // item-row touch counters of the even / odd round (total | remaining)
+    DevBuf<uint32_t> cntp0, cntp1;               // user-row flushes of the even / odd round
+    DevBuf<uint32_t> tab0, tab1;                 // staging-slot tables of the even / odd round (kStageMax words per item row)
+    // staged item rows (2 per event of the widest round) live behind the n item rows in the Q allocation,
+    // so that "new row in place" and "new row to my staging row" are the same store with another offset
+    bool staged = false;                         // the running call uses the staging rows
+    // epoch path: touch metadata of all rounds from one pre-pass (round_kernels.hpp)
+    DevBuf<uint32_t> meta_i, meta_j;
+    DevBuf<unsigned long long> round_rows;
+    DevBuf<uint2> fold, bk_touch;
+    DevBuf<uint32_t> bk_ptr;
+    DevBuf<int64_t> d_bounds;
+    std::vector<int64_t> h_bounds;               // outlives the asynchronous upload
+#ifdef YUE_STAMPS
+    DevBuf<unsigned long long> stamps;           // diagnostic build: phase stamps of one chosen round launch
+    int64_t stamp_launch = -1, update_launches = 0, stamp_waves = 0;
+#endif
+    DevBuf<int32_t> ev_u, ev_i, ev_j, indices;
+    DevBuf<int64_t> indptr;
+    DevBuf<int32_t> xu, xi, xj, xk;      // explicit triplets (replay / rounds), CUNE's fourth row
+    DevBuf<double> x_loss;               // per-step losses (CUNE)
+    DevBuf<float> aU_m, aU_v, aV_m, aV_v;  // Adam moments of the live TF-style path (yue_adam_step); gradients use dP / dQ
+    int64_t adam_m = 0, adam_n = 0; int adam_k = 0;
+    DevBuf<double> scal;                 // [kNllSlots] nll slots + [8] scalars
+    std::vector<int64_t> h_ev_ptr;       // host copy: user -> first event
+    // scoring scratch
+    DevBuf<int32_t> s_users, s_ids, s_mask_idx, s_flags;
+    DevBuf<int64_t> s_mask_ptr;
+    DevBuf<float> s_scores, s_row, s_norms;
+    double scan_ms = 0.0;
+    int64_t scan_events = 0, scan_rescored = 0, scan_tiles_done = 0, scan_tiles_total = 0;
+    DevBuf<unsigned long long> s_work;
+    int scan_used_bf16 = 0;
+    // options (yue_set_option)
+    int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel
+    int opt_scan_batch = 0;              // bf16 scoring kernel: 0 = two tiles per iteration, 256 users per workgroup (default); 1 = one tile, 128 users
+    int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
+    int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
+    int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 2..4: rows with up to that many touches are staged (epoch path)
+    int opt_round_bucket = 0;            // 1: the bucketed pre-pass also for small catalogues (tests)
+    int opt_fold_blocks = 1536;           // workgroups of k_round_fold
+    int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
+    // kernel timing
+    int timing_stride = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int64_t> ev_triplets, ev_launches;
+    size_t ev_used = 0;
+    // FISM (parity path): item-history factors (f64), item factors (f32), item bias (f64)
+    DevBuf<double> fP, fBi, f_coef, f_x, f_hist, f_scores, f_out_sc;
+    DevBuf<float> fQ;
+    DevBuf<int64_t> f_ptr;
+    DevBuf<int32_t> f_items, f_negs, f_ids, f_flags;
+    // FISM rounds: touched-item lists, positions, working copies, difference buffers
+    DevBuf<int64_t> f_uq_ptr, f_neg_ptr;
+    DevBuf<int32_t> f_uq_items, f_loc_i, f_loc_j;
+    DevBuf<float> f_wq, f_dQ;
+    DevBuf<double> f_wp, f_wb, f_dP, f_dB;
+    int64_t fn = 0;
+    int fk = 0;
+    // exact path (chain_host.hip): touch keys / ordinals, runs, granule copies of the factor rows, control words
+    DevBuf<uint32_t> ch_key, ch_val, ch_key2, ch_val2, ch_seg, ch_ord_i, ch_ord_j, ch_head, ch_incl, ch_ord_u, ch_rkey, ch_rval;
+    DevBuf<int64_t> ch_run_ptr, d_ev_ptr;
+    DevBuf<int32_t> ch_run_u;
+    DevBuf<unsigned char> ch_tmp;
+    DevBuf<uint2> ch_Qv, ch_Pv;
+    DevBuf<unsigned long long> ch_ctl;   // [0] run claim counter, [1] validation flags, [2] wait status
+    bool d_ev_ptr_valid = false;
+    int opt_epoch_exact = 0;             // 1: yue_bpr_epoch applies the epoch's triplets with exact sequential semantics (k_bpr_chain)
+    int opt_replay_levels = 0;           // 1: yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path)
+    int opt_chain_waves = 0;             // workgroups per CU of the persistent launch (0: what fits, at most 8)
+    int64_t opt_chain_spin = 0;          // polls per wait before a wave gives up (0: 2^22)
+    int64_t chain_runs = 0, chain_waves = 0, replay_levels = 0;
+    // RCCL
+    ncclComm *comm = nullptr;              // ncclComm_t (comm.hip)
+    int rank = 0, nranks = 1;
+    hipStream_t comm_stream = nullptr;   // (all-reduce +) user-row apply of yue_bpr_epoch run here, beside the next rounds
+    hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
+    hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr;      // brackets of the scoring kernel (yue_get_scan_stats)
+};
+
+namespace yue_host {
+// bpr_host.hip: loss / scalar scratch shared by the training entry points
+int zero_scalars(yue_ctx *c);
+int read_scalars(yue_ctx *c, double *nll, double *sp, double *sq);
+int sumsq_async(yue_ctx *c);
+int upload_triplets(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T, bool validate);
+// comm.hip: sum dP[first .. first + count) over the ranks on `stream` (in place); identity without a communicator
+int reduce_user_block(yue_ctx *c, int64_t first, int64_t count, hipStream_t stream);
+// chain_host.hip: exact sequential semantics over the uploaded events (negatives in ev_j) / over the stream in xu, xi, xj
+int chain_epoch(yue_ctx *c, double lr, double regU, double regI);
+int chain_stream(yue_ctx *c, int64_t T, double lr, double regU, double regI);
+}  // namespace yue_host
