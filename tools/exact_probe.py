@@ -9,7 +9,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from yue_amd import synth                      # noqa: E402
+from yue_amd import _shim                      # noqa: E402
 from yue_amd._shim import Device               # noqa: E402
+if os.environ.get('YUE_LIB'):
+    _shim.LIB_PATH = os.environ['YUE_LIB']
 
 W = {'c3': (1000000, 200000, 50, 128), 'c2': (100000, 50000, 50, 64), 'tiny': (20000, 5000, 20, 128), 'c4shard': (10000000, 125000, 6, 128)}
 

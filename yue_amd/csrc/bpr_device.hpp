@@ -159,4 +159,9 @@ constexpr unsigned long long kTouch = 0x100000001ull;      // +1 touch in both h
 constexpr int kRsrcFlags = 0x00020000;
 constexpr unsigned kStageMax = 4;                          // touches per row served by the staging rows
 
+// TPW consecutive words of an event array, loaded as one block (4-byte alignment: scalar block loads need no more)
+constexpr int kHeaderSlack = 16;           // words of slack the event and metadata arrays carry behind their last event
+template <int TPW>
+struct __attribute__((aligned(4))) HeaderBlock { int32_t w[TPW]; };
+
 }  // namespace yue

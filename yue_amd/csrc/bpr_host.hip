@@ -360,7 +360,7 @@ int upload_triplets(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_
         if (u[t] < 0 || u[t] >= c->m || i[t] < 0 || i[t] >= c->n || j[t] >= c->n)
             return fail(YUE_ERR_ARG, "triplet " + std::to_string(t) + " out of range");
     }
-    HIPCHK(c->xu.resize(T)); HIPCHK(c->xi.resize(T)); HIPCHK(c->xj.resize(T));
+    HIPCHK(c->xu.resize((size_t)T + yue::kHeaderSlack)); HIPCHK(c->xi.resize((size_t)T + yue::kHeaderSlack)); HIPCHK(c->xj.resize((size_t)T + yue::kHeaderSlack));   // (+ slack: header blocks)
     HIPCHK(hipMemcpyAsync(c->xu.p, u, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->xi.p, i, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->xj.p, j, T * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));

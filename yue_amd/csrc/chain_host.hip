@@ -42,7 +42,7 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     if (n * (int64_t)k * 8 >= (1ll << 31)) return fail(YUE_ERR_ARG, "exact path: the granule copy of the item matrix must stay below 2 GiB (n*k*8 < 2^31)");
     if (2 * T >= (1ll << 32)) return fail(YUE_ERR_ARG, "exact path: at most 2^31 - 1 triplets per call");
     HIPCHK(c->ch_key.resize((size_t)(2 * T))); HIPCHK(c->ch_val.resize((size_t)(2 * T)));
-    HIPCHK(c->ch_ord_i.resize((size_t)T)); HIPCHK(c->ch_ord_j.resize((size_t)T));
+    HIPCHK(c->ch_ord_i.resize((size_t)T + yue_host::kHeaderSlackHost)); HIPCHK(c->ch_ord_j.resize((size_t)T + yue_host::kHeaderSlackHost));   // (+ slack: the chain kernel reads whole header blocks)
     HIPCHK(c->ch_ctl.resize(4));
     HIPCHK(hipMemsetAsync(c->ch_ctl.p, 0, 4 * sizeof(unsigned long long), c->stream));
     uint32_t *flags = reinterpret_cast<uint32_t *>(c->ch_ctl.p + 1), *status = reinterpret_cast<uint32_t *>(c->ch_ctl.p + 2);
@@ -71,22 +71,29 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     a.R = R; a.claim = c->ch_ctl.p; a.status = status; a.nll_slots = c->scal.p; a.m = m; a.n = n; a.k = k;
     a.ru = (float)(lr * regU); a.ri = (float)(lr * regI); a.lr = lr;          // BPR.py:55: python-float product, cast to fp32 by NumPy
     a.spin_limit = c->opt_chain_spin > 0 ? (uint32_t)c->opt_chain_spin : (1u << 22);
+#ifdef YUE_CHAIN_STATS
+    HIPCHK(c->ch_stats.resize(8));
+    HIPCHK(hipMemsetAsync(c->ch_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    a.stats = c->ch_stats.p;
+#endif
     // one persistent launch: exactly the waves the chip holds at once (a wave that is not resident cannot be waited for)
     int per_cu = 0, cus = 0;
     const int kr = kr_of(k);
-#define YUE_CHAIN(KR_, PV_) \
-    do { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain<KR_, PV_>, 256, 0)); } while (0)
-    if (ord_u) { if (kr == 1) YUE_CHAIN(1, true); else if (kr == 2) YUE_CHAIN(2, true); else YUE_CHAIN(4, true); }
-    else { if (kr == 1) YUE_CHAIN(1, false); else if (kr == 2) YUE_CHAIN(2, false); else YUE_CHAIN(4, false); }
-#undef YUE_CHAIN
+    const dim3 block(256);
+    dim3 grid(1);
+    // ring of 8 triplets per wave (4 for k > 128: register budget)
+#define YUE_CHAIN_RUN(KR_, PV_, G_)                                                                                                   \
+    do {                                                                                                                                \
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain<KR_, PV_, G_>, 256, 0));                          \
+        per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 8));                                       \
+        grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 3) / 4)));                            \
+        hipLaunchKernelGGL((yue::k_bpr_chain<KR_, PV_, G_>), grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p);  \
+    } while (0)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 8));
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 3) / 4));
-    const dim3 grid((unsigned)blocks), block(256);
-#define YUE_CHAIN(KR_, PV_) hipLaunchKernelGGL((yue::k_bpr_chain<KR_, PV_>), grid, block, 0, c->stream, a)
-    if (ord_u) { if (kr == 1) YUE_CHAIN(1, true); else if (kr == 2) YUE_CHAIN(2, true); else YUE_CHAIN(4, true); }
-    else { if (kr == 1) YUE_CHAIN(1, false); else if (kr == 2) YUE_CHAIN(2, false); else YUE_CHAIN(4, false); }
-#undef YUE_CHAIN
+    if (ord_u) { if (kr == 1) YUE_CHAIN_RUN(1, true, 8); else if (kr == 2) YUE_CHAIN_RUN(2, true, 8); else YUE_CHAIN_RUN(4, true, 4); }
+    else { if (kr == 1) YUE_CHAIN_RUN(1, false, 8); else if (kr == 2) YUE_CHAIN_RUN(2, false, 8); else YUE_CHAIN_RUN(4, false, 4); }
+#undef YUE_CHAIN_RUN
+    const int64_t blocks = grid.x;
     hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, reinterpret_cast<const yue::u32x2 *>(c->ch_Qv.p), c->Q.p, (int64_t)nk);
     if (ord_u) hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, reinterpret_cast<const yue::u32x2 *>(c->ch_Pv.p), c->P.p, (int64_t)mk);
     HIPCHK(hipGetLastError());
@@ -94,6 +101,14 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     HIPCHK(hipMemcpyAsync(ctl, c->ch_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t st = (uint32_t)ctl[2];
+#ifdef YUE_CHAIN_STATS
+    {
+        unsigned long long h[8];
+        HIPCHK(hipMemcpy(h, c->ch_stats.p, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[chain stats] steps without a wait: %llu, %.0f cycles each; steps that waited: %llu (%.2f %%), %.0f cycles each; per run outside the steps: %.0f cycles (%llu runs)\n",
+                h[1], h[1] ? (double)h[0] / h[1] : 0.0, h[3], 100.0 * h[3] / (double)(h[1] + h[3] + 1e-9), h[3] ? (double)h[2] / h[3] : 0.0, h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
+    }
+#endif
     c->chain_runs = R; c->chain_waves = blocks * 4;
     if (st) return fail(YUE_ERR_HIP, std::string("exact path: a wave gave up waiting for a row (") + ((st & 2u) ? "a row's version ran past a waiting touch" : "spin limit") +
                                     "): internal error, the factors on the device are not usable");

@@ -48,7 +48,16 @@ struct ChainArgs {
     float ru, ri;
     double lr;
     uint32_t spin_limit;         // polls a wave spends on ONE wait before it gives up (guards against a hung GPU)
+#ifdef YUE_CHAIN_STATS
+    unsigned long long *stats;   // diagnostic build only (make chainstats): [0] cycles in steps without a wait, [1] such steps,
+                                 // [2] cycles in steps that waited, [3] such steps, [4] cycles per run outside the steps, [5] runs
+#endif
 };
+#ifdef YUE_CHAIN_STATS
+#define YUE_CS(...) __VA_ARGS__
+#else
+#define YUE_CS(...)
+#endif
 
 // Q (fp32 rows) -> granules with version 0, and back.
 __global__ void __launch_bounds__(256) k_chain_pack(const float *X, u32x2 *Xv, int64_t count) {
@@ -110,69 +119,186 @@ __global__ void __launch_bounds__(256) k_chain_runs(const int32_t *ev_u, const u
     if (t == T - 1) run_ptr[incl[t]] = T;
 }
 
+// exp(y) in double for |y| <= 700, as a SHORT dependency chain: this value sits on the critical path of every triplet (the
+// epoch's time is its longest chain of dependent triplets times the latency of one).  Cody-Waite reduction y = n ln2 + r,
+// |r| <= ln2 / 2, the degree-13 Taylor polynomial of exp(r) by Estrin's scheme (4 levels of independent fused multiply-adds
+// instead of 13 dependent ones), ldexp.  Error about 1 ulp -- like the libm value the reference's math.exp returns, it is the
+// fp32 rounding of lr * (1 - s) that enters the factors (a 1-ulp difference in exp moves that rounding once in ~1e8 triplets).
+__device__ __forceinline__ double chain_exp(double y) {
+    const double n = __builtin_rint(y * 1.4426950408889634074);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, y);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    const double r2 = r * r;
+    const double a0 = __builtin_fma(r, 1.0, 1.0), a1 = __builtin_fma(r, 1.0 / 6.0, 0.5), a2 = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0),
+                 a3 = __builtin_fma(r, 1.0 / 5040.0, 1.0 / 720.0), a4 = __builtin_fma(r, 1.0 / 362880.0, 1.0 / 40320.0),
+                 a5 = __builtin_fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0), a6 = __builtin_fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+    const double r4 = r2 * r2;
+    const double b0 = __builtin_fma(a1, r2, a0), b1 = __builtin_fma(a3, r2, a2), b2 = __builtin_fma(a5, r2, a4);
+    const double r8 = r4 * r4;
+    const double c0 = __builtin_fma(b1, r4, b0), c1 = __builtin_fma(a6, r4, b2);
+    return __builtin_ldexp(__builtin_fma(c1, r8, c0), (int)n);
+}
+// 1 / d for a finite d >= 1: hardware reciprocal, two Newton steps, one residual correction (faithful; the division the
+// reference performs is correctly rounded: the two agree except in rare last-bit cases, see chain_exp).
+__device__ __forceinline__ double chain_rcp(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(e, y, y);
+}
+
 // One wave per run.  Lane l holds elements 64 r + l (r < KR) of the three rows, as everywhere in the training kernels; a
 // granule load / store wave-instruction covers 512 contiguous bytes of one row.
-template <int KR, bool PVER>
-__global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a) {
+//
+// The wave walks its run as a software pipeline over a ring of G slots: while triplet t is computed, the item rows of
+// triplets t+1 .. t+G-1 are already in flight (a prefetched row is used only if all its granules carry the triplet's
+// ordinal -- the tag makes speculation free; otherwise the row is polled again), and the (i, j, ordinals) headers of the
+// next group arrive through the scalar unit.  What remains between two dependent triplets of a run is arithmetic.
+//
+// The ring's loads are written as inline assembly with COUNTED waits: the compiler's own wait insertion drains the whole
+// queue (vmcnt(0)) wherever a polling loop joins the straight-line path, which would put a full memory latency back between
+// any two triplets.  Every step of the pipeline issues exactly 2 KR stores and 2 KR loads (out-of-range dummies where an
+// event or a refill does not exist), so the loads of a slot always have (G - 1) * 4 KR younger operations behind them when
+// the slot's turn comes: s_waitcnt vmcnt((G - 1) * 4 KR) is exact.  Anything else the compiler issues in between (re-polls
+// of the slow path, the user row) only adds younger operations or drains: the count stays a lower bound.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define YUE_RING_LOAD(dst, vo, rs, so) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(vo), "s"(rs), "s"(so) : "memory")
+#define YUE_RING_STORE(val, vo, rs, so) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(val), "v"(vo), "s"(rs), "s"(so) : "memory")
+
+template <int KR, int N>
+__device__ __forceinline__ void ring_wait(u32x2 (&gi)[KR], u32x2 (&gj)[KR]) {
+    static_assert(N <= 63, "vmcnt is a 6-bit field");
+    if constexpr (KR == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gi[0]), "+v"(gj[0]) : "n"(N) : "memory");
+    else if constexpr (KR == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gi[0]), "+v"(gi[1]), "+v"(gj[0]), "+v"(gj[1]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(gi[0]), "+v"(gi[1]), "+v"(gi[2]), "+v"(gi[3]), "+v"(gj[0]), "+v"(gj[1]), "+v"(gj[2]), "+v"(gj[3]) : "n"(N) : "memory");
+}
+
+template <int KR, bool PVER, int G>
+__global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
+                                                   const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
     const int lane = threadIdx.x & 63;
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = k * 8u;                   // granule rows
     unsigned vo[KR];
 #pragma unroll
     for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; vo[r] = e < k ? e * 8u : kOobOffset; }
+    const unsigned v_oob = kOobOffset;
     const uint64_t qbytes = (uint64_t)a.n * row_bytes;
-    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(a.Qv, 0, (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull), kRsrcFlags);
-    double nll = 0.0;
+    const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
+    i32x4 rq;                                            // the same descriptor as plain words, for the assembly operands
+    { const uint64_t qa = (uint64_t)a.Qv; rq.x = (int)(uint32_t)qa; rq.y = (int)((uint32_t)(qa >> 32) & 0xffffu); rq.z = qrec; rq.w = kRsrcFlags; }
+    double nl = 0.0;                                     // per-lane partial of sum -log(s)
+    double sv = 1.0;                                     // lane q keeps the sigmoid of the q-th triplet since the last flush
+    unsigned nsv = 0;                                    // (the logs are taken 64 at a time, off the dependency chain)
     uint64_t wave_slot = 0;
+    bool dead = false;
+    YUE_CS(unsigned long long cs_fast = 0, cs_nfast = 0, cs_slow = 0, cs_nslow = 0, cs_run = 0, cs_nrun = 0;)
 
-    // Waits until all k granules of a row carry `want`; returns false if the wave gave up (status set).
-    // The row is in g[] afterwards.  Far from its turn (the row's version says how far) a wave sleeps in proportion and
-    // polls ONE granule; only the next toucher re-reads the whole row.
-    auto acquire = [&](const decltype(rsQ) &rs, unsigned so, uint32_t want, u32x2 (&g)[KR]) -> bool {
+    auto all_mine = [&](uint32_t want, const u32x2 (&g)[KR]) -> bool {
+        bool mine = true;
+#pragma unroll
+        for (int r = 0; r < KR; ++r) mine = mine && (vo[r] == kOobOffset || g[r].y == want);
+        return __builtin_amdgcn_ballot_w64(!mine) == 0ull;
+    };
+    // Slow path of a wait: polls until all k granules of the row carry `want`; false if the wave gave up (status set).
+    // Far from its turn (the row's version says how far) a wave sleeps in proportion and polls ONE granule; only the next
+    // toucher re-reads the whole row.
+    // (its loads are assembly with their own full waits as well: a compiler-tracked load here would make the compiler drain
+    // the queue where this path joins the straight-line one)
+    auto acquire_slow = [&](const i32x4 &rs, unsigned so, uint32_t want, u32x2 (&g)[KR]) -> bool {
         uint32_t polls = 0;
+        bool fresh = false;                                      // g is the prefetch of several triplets ago: its version says nothing yet
         for (;;) {
-#pragma unroll
-            for (int r = 0; r < KR; ++r) g[r] = YUE_GLOAD(rs, vo[r], so);
-            bool mine = true;
-#pragma unroll
-            for (int r = 0; r < KR; ++r) mine = mine && (vo[r] == kOobOffset || g[r].y == want);
-            if (__builtin_amdgcn_ballot_w64(!mine) == 0ull) return true;
             // how far away is my turn?  (granule 0 of the row; a row in the middle of a rewrite reads as distance 0)
-            uint32_t dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)g[0].y);
+            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)g[0].y) : 0u;
+            fresh = true;
             while ((int32_t)dist > 1) {
-                // ~0.8 us per touch in front of me, capped (the sleeps below add up to at most ~14 us)
-                const uint32_t naps = dist < 16u ? dist : 16u;
-                for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(32);
-                const u32x2 one = YUE_GLOAD(rs, lane == 0 ? 0u : kOobOffset, so);
+                const uint32_t naps = dist < 16u ? dist : 16u;      // ~0.5 us per touch in front of me, capped
+                for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(20);
+                u32x2 one;
+                const unsigned v1 = lane == 0 ? 0u : kOobOffset;
+                YUE_RING_LOAD(one, v1, rs, so);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(one) :: "memory");
                 dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)one.y);
-                if (++polls > a.spin_limit || (int32_t)dist < 0) { if (lane == 0) atomicOr(a.status, (int32_t)dist < 0 ? 2u : 1u); return false; }
+                if (++polls > a.spin_limit || (int32_t)dist < 0) break;
                 if ((polls & 63u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             }
-            if ((int32_t)dist < 0) { if (lane == 0) atomicOr(a.status, 2u); return false; }
-            __builtin_amdgcn_s_sleep(2);
-            if (++polls > a.spin_limit) { if (lane == 0) atomicOr(a.status, 1u); return false; }
+            if ((int32_t)dist < 0 || ++polls > a.spin_limit) { if (lane == 0) atomicOr(a.status, (int32_t)dist < 0 ? 2u : 1u); return false; }
             if ((polls & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) YUE_RING_LOAD(g[r], vo[r], rs, so);
+            if constexpr (KR == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]) :: "memory");
+            else if constexpr (KR == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) :: "memory");
+            if (all_mine(want, g)) return true;
         }
     };
+    auto flush_logs = [&]() {
+        if ((unsigned)lane < nsv) nl += -log(sv);                    // BPR.py:58
+        nsv = 0;
+    };
 
-    for (;;) {
+    while (!dead) {
         unsigned long long run = 0;
         if (lane == 0) run = atomicAdd(a.claim, 1ull);
         run = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(run >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)run);
         if ((int64_t)run >= a.R) break;
+        YUE_CS(const unsigned long long cs_r0 = __builtin_readcyclecounter(); unsigned long long cs_steps = 0;)
         wave_slot = run;
         const int64_t e0 = a.run_ptr[run], e1 = a.run_ptr[run + 1];
         if (e1 <= e0) continue;
         const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
+
+        // headers of the first two groups, rows of the first group
+        int hi[2][G], hj[2][G];
+        uint32_t hwi[2][G], hwj[2][G];
+        auto load_header = [&](int which, int64_t base) {
+            const HeaderBlock<G> bi = *reinterpret_cast<const HeaderBlock<G> *>(evi + base);
+            const HeaderBlock<G> bj = *reinterpret_cast<const HeaderBlock<G> *>(evj + base);
+            const HeaderBlock<G> bwi = *reinterpret_cast<const HeaderBlock<G> *>(ordi + base);
+            const HeaderBlock<G> bwj = *reinterpret_cast<const HeaderBlock<G> *>(ordj + base);
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                const bool ex = base + s < e1;
+                hi[which][s] = ex ? bi.w[s] : 0; hj[which][s] = ex ? bj.w[s] : -1;
+                hwi[which][s] = (uint32_t)bwi.w[s]; hwj[which][s] = (uint32_t)bwj.w[s];
+            }
+        };
+        auto no_header = [&](int which) {
+#pragma unroll
+            for (int s = 0; s < G; ++s) { hi[which][s] = 0; hj[which][s] = -1; hwi[which][s] = hwj[which][s] = 0u; }
+        };
+        u32x2 gi[G][KR], gj[G][KR];
+        // loads of one slot: 2 KR ring loads, real ones for an event with a negative, out-of-range dummies otherwise
+        auto fill = [&](int which, int s) {
+            const bool live = hj[which][s] >= 0;
+            const unsigned oi = live ? (unsigned)hi[which][s] * row_bytes : 0u, oj = live ? (unsigned)hj[which][s] * row_bytes : 0u;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const unsigned v = live ? vo[r] : v_oob;
+                YUE_RING_LOAD(gj[s][r], v, rq, oj); YUE_RING_LOAD(gi[s][r], v, rq, oi);
+            }
+        };
+        load_header(0, e0);
+#pragma unroll
+        for (int s = 0; s < G; ++s) fill(0, s);
+        if (e0 + G < e1) load_header(1, e0 + G); else no_header(1);
 
         float p[KR];
         uint32_t pver = 0u;
         if (PVER) {
             // user rows as granules, addressed through a descriptor based at the row (any number of users)
             const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.Pv + (uint64_t)u * k, 0, (int)row_bytes, kRsrcFlags);
+            i32x4 rp;
+            { const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * k); rp.x = (int)(uint32_t)pa; rp.y = (int)((uint32_t)(pa >> 32) & 0xffffu); rp.z = (int)row_bytes; rp.w = kRsrcFlags; }
             pver = a.ord_u[run];
             u32x2 g[KR];
-            if (!acquire(rsP, 0u, pver, g)) return;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) g[r] = YUE_GLOAD(rsP, vo[r], 0u);
+            if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) { dead = true; break; }
 #pragma unroll
             for (int r = 0; r < KR; ++r) p[r] = __builtin_bit_cast(float, g[r].x);
         } else {
@@ -180,36 +306,66 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a) {
 #pragma unroll
             for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; p[r] = e < k ? prow[e] : 0.0f; }
         }
+        // (an empty statement that reads p: the compiler places ITS wait for the user row's loads here, not in front of every
+        // step's arithmetic, where it would drain the ring)
+#pragma unroll
+        for (int r = 0; r < KR; ++r) asm volatile("" : "+v"(p[r]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the ring is full: from here on the counted waits hold
 
-        for (int64_t e = e0; e < e1; ++e) {
-            const int32_t i = a.ev_i[e], j = a.ev_j[e];
-            if (j < 0) continue;                                     // the sampler gave up on this event (BPR.py:47 would spin)
-            const uint32_t wi = a.ord_i[e], wj = a.ord_j[e];
-            const unsigned oi = (unsigned)i * row_bytes, oj = (unsigned)j * row_bytes;
-            u32x2 gi[KR], gj[KR];
-            if (!acquire(rsQ, oj, wj, gj)) return;                   // the negative is almost always a cold row: first
-            if (!acquire(rsQ, oi, wi, gi)) return;
-            float qi[KR], qj[KR];
+        for (int64_t base = e0; base < e1 && !dead; base += G) {
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { qi[r] = __builtin_bit_cast(float, gi[r].x); qj[r] = __builtin_bit_cast(float, gj[r].x); }
-            float ai = 0.0f, aj = 0.0f;
+            for (int s = 0; s < G; ++s) {
+                YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter(); bool cs_waited = false;)
+                ring_wait<KR, (G - 1) * 4 * KR>(gi[s], gj[s]);
+                bool done = false;
+                if (hj[0][s] >= 0 && !dead) {                        // (wave-uniform) an event of the run with a negative
+                    const uint32_t wi = hwi[0][s], wj = hwj[0][s];
+                    const unsigned oi = (unsigned)hi[0][s] * row_bytes, oj = (unsigned)hj[0][s] * row_bytes;
+                    bool ok = true;
+                    if (!all_mine(wj, gj[s])) { ok = acquire_slow(rq, oj, wj, gj[s]); YUE_CS(cs_waited = true;) }
+                    if (ok && !all_mine(wi, gi[s])) { ok = acquire_slow(rq, oi, wi, gi[s]); YUE_CS(cs_waited = true;) }
+                    if (!ok) dead = true;
+                    else {
+                        float qi[KR], qj[KR];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { const float a1 = p[r] * qi[r]; ai = ai + a1; const float a2 = p[r] * qj[r]; aj = aj + a2; }
-            const float x = wave_sum(ai) - wave_sum(aj);             // BPR.py:50, fp32 margin
-            const double s = 1.0 / (1.0 + exp(-(double)x));          // qmath.py:115-116
-            const float c = (float)(a.lr * (1.0 - s));
+                        for (int r = 0; r < KR; ++r) { qi[r] = __builtin_bit_cast(float, gi[s][r].x); qj[r] = __builtin_bit_cast(float, gj[s][r].x); }
+                        float ai = 0.0f, aj = 0.0f;
 #pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                const Elem o = bpr_elem(p[r], qi[r], qj[r], c, a.ru, a.ri);
-                p[r] = o.p2;
-                u32x2 ni, nj;
-                ni.x = __builtin_bit_cast(unsigned, o.qi2); ni.y = wi + 1u;
-                nj.x = __builtin_bit_cast(unsigned, o.qj2); nj.y = wj + 1u;
-                YUE_GSTORE(ni, rsQ, vo[r], oi);                      // the hot row first: its next toucher is waiting
-                YUE_GSTORE(nj, rsQ, vo[r], oj);
+                        for (int r = 0; r < KR; ++r) { const float a1 = p[r] * qi[r]; ai = ai + a1; const float a2 = p[r] * qj[r]; aj = aj + a2; }
+                        const float x = wave_sum(ai) - wave_sum(aj);                 // BPR.py:50, fp32 margin
+                        const double xd = (double)x;
+                        double sg;
+                        if (__builtin_fabs(xd) <= 700.0) sg = chain_rcp(1.0 + chain_exp(-xd));     // qmath.py:115-116
+                        else sg = 1.0 / (1.0 + exp(-xd));
+                        const float c = (float)(a.lr * (1.0 - sg));
+#pragma unroll
+                        for (int r = 0; r < KR; ++r) {
+                            const Elem o = bpr_elem(p[r], qi[r], qj[r], c, a.ru, a.ri);
+                            p[r] = o.p2;
+                            u32x2 ni, nj;
+                            ni.x = __builtin_bit_cast(unsigned, o.qi2); ni.y = wi + 1u;
+                            nj.x = __builtin_bit_cast(unsigned, o.qj2); nj.y = wj + 1u;
+                            YUE_RING_STORE(ni, vo[r], rq, oi);                       // the positive's row first: the hotter of the two
+                            YUE_RING_STORE(nj, vo[r], rq, oj);
+                        }
+                        sv = (unsigned)lane == nsv ? sg : sv;
+                        if (++nsv == 64u) flush_logs();
+                        done = true;
+                    }
+                }
+                if (!done) {                                         // no event in this slot: the step's stores as dummies
+                    u32x2 z; z.x = 0u; z.y = 0u;
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) { YUE_RING_STORE(z, v_oob, rq, 0u); YUE_RING_STORE(z, v_oob, rq, 0u); }
+                }
+                fill(1, s);                                          // refill the slot with the same slot of the next group
+                YUE_CS(if (done) { const unsigned long long dt = __builtin_readcyclecounter() - cs_t0; cs_steps += dt; if (cs_waited) { cs_slow += dt; ++cs_nslow; } else { cs_fast += dt; ++cs_nfast; } })
             }
-            nll += -log(s);                                          // BPR.py:58 (behind the stores: off the hand-off path)
+#pragma unroll
+            for (int s = 0; s < G; ++s) { hi[0][s] = hi[1][s]; hj[0][s] = hj[1][s]; hwi[0][s] = hwi[1][s]; hwj[0][s] = hwj[1][s]; }
+            if (base + 2 * G < e1) load_header(1, base + 2 * G); else no_header(1);
         }
+        if (dead) break;
 
         if (PVER) {
             const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.Pv + (uint64_t)u * k, 0, (int)row_bytes, kRsrcFlags);
@@ -220,8 +376,14 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a) {
 #pragma unroll
             for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; if (e < k) prow[e] = p[r]; }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing of this run's ring is in flight when the next run refills it
+        YUE_CS(cs_run += __builtin_readcyclecounter() - cs_r0 - cs_steps; ++cs_nrun;)
     }
-    if (lane == 0 && nll != 0.0) atomicAdd(a.nll_slots + (wave_slot & (kNllSlots - 1)), nll);
+    YUE_CS(if (lane == 0) { atomicAdd(a.stats + 0, cs_fast); atomicAdd(a.stats + 1, cs_nfast); atomicAdd(a.stats + 2, cs_slow); atomicAdd(a.stats + 3, cs_nslow); atomicAdd(a.stats + 4, cs_run); atomicAdd(a.stats + 5, cs_nrun); })
+    flush_logs();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nl += __shfl_xor(nl, off);
+    if (lane == 0 && nl != 0.0) atomicAdd(a.nll_slots + (wave_slot & (kNllSlots - 1)), nl);
 }
 
 }  // namespace yue

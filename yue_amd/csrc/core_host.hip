@@ -65,7 +65,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->f_wq.release(); c->f_dQ.release(); c->f_wp.release(); c->f_wb.release(); c->f_dP.release(); c->f_dB.release();
     c->ch_key.release(); c->ch_val.release(); c->ch_key2.release(); c->ch_val2.release(); c->ch_seg.release(); c->ch_ord_i.release(); c->ch_ord_j.release();
     c->ch_head.release(); c->ch_incl.release(); c->ch_ord_u.release(); c->ch_rkey.release(); c->ch_rval.release(); c->ch_run_ptr.release(); c->d_ev_ptr.release();
-    c->ch_run_u.release(); c->ch_tmp.release(); c->ch_Qv.release(); c->ch_Pv.release(); c->ch_ctl.release();
+    c->ch_run_u.release(); c->ch_tmp.release(); c->ch_Qv.release(); c->ch_Pv.release(); c->ch_ctl.release(); c->ch_stats.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return YUE_OK;

@@ -126,6 +126,7 @@ struct yue_ctx {
     DevBuf<unsigned char> ch_tmp;
     DevBuf<uint2> ch_Qv, ch_Pv;
     DevBuf<unsigned long long> ch_ctl;   // [0] run claim counter, [1] validation flags, [2] wait status
+    DevBuf<unsigned long long> ch_stats; // diagnostic build (make chainstats) only
     bool d_ev_ptr_valid = false;
     int opt_epoch_exact = 0;             // 1: yue_bpr_epoch applies the epoch's triplets with exact sequential semantics (k_bpr_chain)
     int opt_replay_levels = 0;           // 1: yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path)

@@ -274,10 +274,6 @@ __global__ void __launch_bounds__(1024) k_round_bucket(BucketArgs a) {
     }
 }
 
-// TPW consecutive words of an event array, loaded as one block (4-byte alignment: scalar block loads need no more)
-constexpr int kHeaderSlack = 16;           // words of slack the event and metadata arrays carry behind their last event
-template <int TPW>
-struct __attribute__((aligned(4))) HeaderBlock { int32_t w[TPW]; };
 
 struct RoundMArgs {
     int64_t e_begin, e_end;      // events updated by this launch
