@@ -67,8 +67,10 @@ int yue_get_factors(yue_ctx *ctx, float *P, float *Q);
 int yue_set_interactions(yue_ctx *ctx, const int64_t *indptr, const int32_t *indices,
                          const int64_t *ev_ptr, const int32_t *ev_i);
 
-/* Exact sequential semantics of BPR.py:42-58 on explicit triplets (dependency-levelled on the
- * device).  j[t] < 0 skips the triplet.  nll_out = sum of -log(s). */
+/* Exact sequential semantics of BPR.py:42-58 on explicit triplets, any order of users: one dataflow launch in which every
+ * triplet waits for exactly the earlier triplets that share a row with it (chain_kernels.hpp; row ordinals and runs of
+ * equal users are computed on the device, the host only copies the stream up).  j[t] < 0 skips the triplet.
+ * nll_out = sum of -log(s).  Ids are checked on the device before anything is written. */
 int yue_bpr_replay(yue_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j, int64_t T,
                    double lr, double regU, double regI, double *nll_out);
 
@@ -170,6 +172,15 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *               inside the round launches (k_round, the kernel of yue_bpr_rounds).  Also moves yue_default_round_events.
  *   "round_bucket" 1: the bucketed pre-pass also for small catalogues (tests)
  *   "fold_blocks" workgroups of the fold launch (default 1536)
+ *   "chain_waves" exact path: workgroups (of four waves) per CU of the dataflow launch, 1..8 (0 = default: 1)
+ *   "chain_spin"  exact path: polls a wave spends on one wait before it gives up with an error (0 = default: 2^22)
+ * Behaviour switches:
+ *   "epoch_exact" 1 = yue_bpr_epoch applies the epoch's triplets (device sampler's negatives) with the reference's exact
+ *               sequential semantics (recommender/cf/BPR.py:42-58) instead of S-rounds: round_events is ignored, one GPU only
+ *   "replay_levels" 1 = yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path, kept for
+ *               comparison; same results)
+ * Read-only (yue_get_option): "chain_last_runs" / "chain_last_waves" (runs walked / waves launched by the last exact launch),
+ *   "replay_last_levels" (dependency levels of the last levelled replay)
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
  *               the reference's order-dependent overwrite-scan */

@@ -39,7 +39,6 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
                  const uint32_t *ord_u, int64_t R, double lr, double regU, double regI) {
     const int64_t n = c->n, m = c->m;
     const int k = c->k;
-    if (n * (int64_t)k * 8 >= (1ll << 31)) return fail(YUE_ERR_ARG, "exact path: the granule copy of the item matrix must stay below 2 GiB (n*k*8 < 2^31)");
     if (2 * T >= (1ll << 32)) return fail(YUE_ERR_ARG, "exact path: at most 2^31 - 1 triplets per call");
     HIPCHK(c->ch_key.resize((size_t)(2 * T))); HIPCHK(c->ch_val.resize((size_t)(2 * T)));
     HIPCHK(c->ch_ord_i.resize((size_t)T + yue_host::kHeaderSlackHost)); HIPCHK(c->ch_ord_j.resize((size_t)T + yue_host::kHeaderSlackHost));   // (+ slack: the chain kernel reads whole header blocks)
@@ -58,15 +57,16 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
         if (fl & 2u) return fail(YUE_ERR_ARG, "a triplet has i == j");
     }
     // item rows -> granules (and the user rows, when a user may have several runs)
-    const size_t nk = (size_t)n * k, mk = (size_t)m * k;
-    HIPCHK(c->ch_Qv.resize(nk));
-    hipLaunchKernelGGL(yue::k_chain_pack, dim3(2048), dim3(256), 0, c->stream, c->Q.p, reinterpret_cast<yue::u32x2 *>(c->ch_Qv.p), (int64_t)nk);
+    const size_t gwords = (size_t)yue::chain_granules_per_row(k) * 2;      // 32-bit words of a granule row
+    if (n * (int64_t)gwords * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "exact path: the granule copy of the item matrix must stay below 2 GiB");
+    HIPCHK(c->ch_Qv.resize((size_t)n * gwords));
+    hipLaunchKernelGGL(yue::k_chain_pack, dim3(2048), dim3(256), 0, c->stream, c->Q.p, c->ch_Qv.p, n, k);
     if (ord_u) {
-        HIPCHK(c->ch_Pv.resize(mk));
-        hipLaunchKernelGGL(yue::k_chain_pack, dim3(2048), dim3(256), 0, c->stream, c->P.p, reinterpret_cast<yue::u32x2 *>(c->ch_Pv.p), (int64_t)mk);
+        HIPCHK(c->ch_Pv.resize((size_t)m * gwords));
+        hipLaunchKernelGGL(yue::k_chain_pack, dim3(2048), dim3(256), 0, c->stream, c->P.p, c->ch_Pv.p, m, k);
     }
     yue::ChainArgs a{};
-    a.P = c->P.p; a.Pv = ord_u ? reinterpret_cast<yue::u32x2 *>(c->ch_Pv.p) : nullptr; a.Qv = reinterpret_cast<yue::u32x2 *>(c->ch_Qv.p);
+    a.P = c->P.p; a.Pv = ord_u ? c->ch_Pv.p : nullptr; a.Qv = c->ch_Qv.p;
     a.run_ptr = run_ptr; a.run_u = run_u; a.ord_u = ord_u; a.ev_i = ev_i; a.ev_j = ev_j; a.ord_i = c->ch_ord_i.p; a.ord_j = c->ch_ord_j.p;
     a.R = R; a.claim = c->ch_ctl.p; a.status = status; a.nll_slots = c->scal.p; a.m = m; a.n = n; a.k = k;
     a.ru = (float)(lr * regU); a.ri = (float)(lr * regI); a.lr = lr;          // BPR.py:55: python-float product, cast to fp32 by NumPy
@@ -76,7 +76,10 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     HIPCHK(hipMemsetAsync(c->ch_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
     a.stats = c->ch_stats.p;
 #endif
-    // one persistent launch: exactly the waves the chip holds at once (a wave that is not resident cannot be waited for)
+    // One persistent launch of resident waves only (a wave that is not resident cannot be waited for).  Default: ONE wave per
+    // SIMD (one workgroup of four per CU, 1,024 waves on MI355X): the epoch's time is its longest chain of dependent triplets
+    // times the latency of a step, and a wave alone on its SIMD has the shortest step (measured on BASELINE config 3:
+    // 913 ms per epoch with 1,024 waves, 1,131 ms with 3,072; option chain_waves = workgroups per CU).
     int per_cu = 0, cus = 0;
     const int kr = kr_of(k);
     const dim3 block(256);
@@ -85,7 +88,7 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
 #define YUE_CHAIN_RUN(KR_, PV_, G_)                                                                                                   \
     do {                                                                                                                                \
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain<KR_, PV_, G_>, 256, 0));                          \
-        per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 8));                                       \
+        per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 1));                                       \
         grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 3) / 4)));                            \
         hipLaunchKernelGGL((yue::k_bpr_chain<KR_, PV_, G_>), grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p);  \
     } while (0)
@@ -94,8 +97,8 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     else { if (kr == 1) YUE_CHAIN_RUN(1, false, 8); else if (kr == 2) YUE_CHAIN_RUN(2, false, 8); else YUE_CHAIN_RUN(4, false, 4); }
 #undef YUE_CHAIN_RUN
     const int64_t blocks = grid.x;
-    hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, reinterpret_cast<const yue::u32x2 *>(c->ch_Qv.p), c->Q.p, (int64_t)nk);
-    if (ord_u) hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, reinterpret_cast<const yue::u32x2 *>(c->ch_Pv.p), c->P.p, (int64_t)mk);
+    hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, c->ch_Qv.p, c->Q.p, n, k);
+    if (ord_u) hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, c->ch_Pv.p, c->P.p, m, k);
     HIPCHK(hipGetLastError());
     unsigned long long ctl[4];
     HIPCHK(hipMemcpyAsync(ctl, c->ch_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));

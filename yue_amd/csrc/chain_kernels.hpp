@@ -5,11 +5,12 @@
 // k_bpr_chain runs exactly that partial order and nothing more:
 //   * a pre-pass (chain_host.hip) gives every touch of an item row its ORDINAL: the number of earlier touches of that row
 //     in the stream (a stable sort of the 2T touches by row);
-//   * item rows live in a versioned copy Qv: every element is one naturally aligned 8-byte granule {fp32 value, version},
-//     version = number of touches the row has received so far.  A granule is written by ONE sc1 (write-through) store
-//     and read by sc1 loads: the hand-off needs no flag, no fence and no drain -- a reader that finds version == its
-//     ordinal on all k granules holds exactly the row its predecessor wrote (MI355X_MICROARCH.md, price list: handoff-1to1,
-//     "data-tagged granules"; ~1-3 us per hop);
+//   * item rows live in a versioned copy Qv made of naturally aligned GRANULES {values, version}: version = number of
+//     touches the row has received so far.  A granule is 8 bytes {element, version}, written by ONE sc1 (write-through)
+//     store and read by sc1 loads: the hand-off needs no flag, no fence and no drain -- a reader that finds version == its
+//     ordinal on all granules of a row holds exactly the row its predecessor wrote (MI355X_MICROARCH.md, price list:
+//     handoff-1to1, "data-tagged granules"; ~1-3 us per hop).  (A 16-byte granule {value, value, version} was tried: its
+//     8-byte halves do tear -- one wrong row in ~1e5 showed up in the loss.)
 //   * one wave walks one RUN of consecutive triplets with the same user (user-major events: a run = a user), P[u] stays in
 //     registers for the whole run; per triplet it waits until both item rows carry its ordinals, applies the reference's
 //     update (bpr_device.hpp: same arithmetic as every other training kernel), and stores the two rows with version + 1;
@@ -32,8 +33,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct ChainArgs {
     float *P;                    // user rows, plain fp32 (ord_u == nullptr: every user has at most one run)
-    u32x2 *Pv;                   // user rows as granules (general streams)
-    u32x2 *Qv;                   // item rows as granules {value bits, version}
+    unsigned *Pv;                // user rows as granules (general streams)
+    unsigned *Qv;                // item rows as granules {values, version}
     const int64_t *run_ptr;      // [R + 1] triplet offsets of the runs
     const int32_t *run_u;        // [R] user of a run; nullptr: run r is user r (the uploaded events, user-major)
     const uint32_t *ord_u;       // [R] runs of the same user before this one; nullptr with plain P
@@ -59,17 +60,24 @@ struct ChainArgs {
 #define YUE_CS(...)
 #endif
 
-// Q (fp32 rows) -> granules with version 0, and back.
-__global__ void __launch_bounds__(256) k_chain_pack(const float *X, u32x2 *Xv, int64_t count) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
-        u32x2 g; g.x = __builtin_bit_cast(unsigned, X[t]); g.y = 0u;
-        Xv[t] = g;
+// Rows (fp32, k elements) -> granule rows of 64 * KR granules {element e, version 0} (value 0 for e >= k), and back.
+__host__ __device__ inline int chain_granules_per_row(int k) { return k <= 64 ? 64 : k <= 128 ? 128 : 256; }
+__global__ void __launch_bounds__(256) k_chain_pack(const float *X, unsigned *Xv, int64_t rows, int k) {
+    const int gpr = chain_granules_per_row(k);
+    const int64_t total = rows * gpr, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t row = t / gpr; const int e = (int)(t - row * gpr);
+        u32x2 g; g.x = e < k ? __builtin_bit_cast(unsigned, X[row * k + e]) : 0u; g.y = 0u;
+        reinterpret_cast<u32x2 *>(Xv)[t] = g;
     }
 }
-__global__ void __launch_bounds__(256) k_chain_unpack(const u32x2 *Xv, float *X, int64_t count) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) X[t] = __builtin_bit_cast(float, Xv[t].x);
+__global__ void __launch_bounds__(256) k_chain_unpack(const unsigned *Xv, float *X, int64_t rows, int k) {
+    const int gpr = chain_granules_per_row(k);
+    const int64_t total = rows * gpr, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t row = t / gpr; const int e = (int)(t - row * gpr);
+        if (e < k) X[row * k + e] = __builtin_bit_cast(float, Xv[2 * t]);
+    }
 }
 
 // Ordinals from the stably sorted touches: sorted position p holds (row key[p], touch code val[p] = 2 * triplet + side).
@@ -150,45 +158,63 @@ __device__ __forceinline__ double chain_rcp(double d) {
     return __builtin_fma(e, y, y);
 }
 
-// One wave per run.  Lane l holds elements 64 r + l (r < KR) of the three rows, as everywhere in the training kernels; a
-// granule load / store wave-instruction covers 512 contiguous bytes of one row.
+// One wave per run.  Lane l holds elements 64 r + l (r < KR) of the three rows, as everywhere in the training kernels.
 //
 // The wave walks its run as a software pipeline over a ring of G slots: while triplet t is computed, the item rows of
 // triplets t+1 .. t+G-1 are already in flight (a prefetched row is used only if all its granules carry the triplet's
-// ordinal -- the tag makes speculation free; otherwise the row is polled again), and the (i, j, ordinals) headers of the
-// next group arrive through the scalar unit.  What remains between two dependent triplets of a run is arithmetic.
+// ordinal -- the tag makes speculation free; otherwise the row is polled again).  The (i, j, ordinals) headers of up to 64
+// triplets sit in the lanes of four registers (one vector load each per segment of 64, a v_readlane per use).  What remains
+// between two dependent triplets of a run is arithmetic.
 //
-// The ring's loads are written as inline assembly with COUNTED waits: the compiler's own wait insertion drains the whole
+// The ring's loads and stores are inline assembly with COUNTED waits: the compiler's own wait insertion drains the whole
 // queue (vmcnt(0)) wherever a polling loop joins the straight-line path, which would put a full memory latency back between
-// any two triplets.  Every step of the pipeline issues exactly 2 KR stores and 2 KR loads (out-of-range dummies where an
-// event or a refill does not exist), so the loads of a slot always have (G - 1) * 4 KR younger operations behind them when
-// the slot's turn comes: s_waitcnt vmcnt((G - 1) * 4 KR) is exact.  Anything else the compiler issues in between (re-polls
-// of the slow path, the user row) only adds younger operations or drains: the count stays a lower bound.
+// any two triplets.  Every step of the pipeline issues exactly 2 GR stores and 2 GR loads (out-of-range dummies where an
+// event or a refill does not exist), so the loads of a slot always have (G - 1) * 4 GR younger operations behind them when
+// the slot's turn comes: s_waitcnt vmcnt((G - 1) * 4 GR) is exact.  Anything issued in between (re-polls of the slow path)
+// only adds younger operations or drains: the count stays a lower bound.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-#define YUE_RING_LOAD(dst, vo, rs, so) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(vo), "s"(rs), "s"(so) : "memory")
-#define YUE_RING_STORE(val, vo, rs, so) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(val), "v"(vo), "s"(rs), "s"(so) : "memory")
 
-template <int KR, int N>
-__device__ __forceinline__ void ring_wait(u32x2 (&gi)[KR], u32x2 (&gj)[KR]) {
+struct Gran {
+    typedef u32x2 reg; typedef float val;
+    static __device__ __forceinline__ void load(reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(d) : "v"(vo), "s"(rs), "s"(so) : "memory"); }
+    static __device__ __forceinline__ void store(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory"); }
+    static __device__ __forceinline__ val value(const reg &d) { return __builtin_bit_cast(float, d.x); }
+    static __device__ __forceinline__ bool is(const reg &d, unsigned want) { return d.y == want; }
+    static __device__ __forceinline__ unsigned version(const reg &d) { return d.y; }
+    static __device__ __forceinline__ reg make(val v, unsigned ver) { reg d; d.x = __builtin_bit_cast(unsigned, v); d.y = ver; return d; }
+};
+
+template <int GR, int N, typename R>
+__device__ __forceinline__ void ring_wait(R (&gi)[GR], R (&gj)[GR]) {
     static_assert(N <= 63, "vmcnt is a 6-bit field");
-    if constexpr (KR == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gi[0]), "+v"(gj[0]) : "n"(N) : "memory");
-    else if constexpr (KR == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gi[0]), "+v"(gi[1]), "+v"(gj[0]), "+v"(gj[1]) : "n"(N) : "memory");
+    if constexpr (GR == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gi[0]), "+v"(gj[0]) : "n"(N) : "memory");
+    else if constexpr (GR == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gi[0]), "+v"(gi[1]), "+v"(gj[0]), "+v"(gj[1]) : "n"(N) : "memory");
     else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(gi[0]), "+v"(gi[1]), "+v"(gi[2]), "+v"(gi[3]), "+v"(gj[0]), "+v"(gj[1]), "+v"(gj[2]), "+v"(gj[3]) : "n"(N) : "memory");
+}
+template <int GR, typename R>
+__device__ __forceinline__ void row_wait_all(R (&g)[GR]) {
+    if constexpr (GR == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]) :: "memory");
+    else if constexpr (GR == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) :: "memory");
 }
 
 template <int KR, bool PVER, int G>
 __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                    const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
+    constexpr int GR = KR, GB = 8;                       // granules per lane and row, granule bytes
+    typedef Gran GT;
+    typedef typename GT::reg greg;
+    typedef typename GT::val gval;
     const int lane = threadIdx.x & 63;
     const unsigned k = (unsigned)a.k;
-    const unsigned row_bytes = k * 8u;                   // granule rows
-    unsigned vo[KR];
+    const unsigned row_bytes = (unsigned)GR * 64u * GB;  // granule rows
+    unsigned vo[GR];
 #pragma unroll
-    for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; vo[r] = e < k ? e * 8u : kOobOffset; }
+    for (int g = 0; g < GR; ++g) vo[g] = (64u * g + lane) * GB;      // (elements beyond k are zero-valued granules of the copy: no masking here)
     const unsigned v_oob = kOobOffset;
     const uint64_t qbytes = (uint64_t)a.n * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
-    i32x4 rq;                                            // the same descriptor as plain words, for the assembly operands
+    i32x4 rq;                                            // buffer descriptor of Qv as plain words, for the assembly operands
     { const uint64_t qa = (uint64_t)a.Qv; rq.x = (int)(uint32_t)qa; rq.y = (int)((uint32_t)(qa >> 32) & 0xffffu); rq.z = qrec; rq.w = kRsrcFlags; }
     double nl = 0.0;                                     // per-lane partial of sum -log(s)
     double sv = 1.0;                                     // lane q keeps the sigmoid of the q-th triplet since the last flush
@@ -197,42 +223,39 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
     bool dead = false;
     YUE_CS(unsigned long long cs_fast = 0, cs_nfast = 0, cs_slow = 0, cs_nslow = 0, cs_run = 0, cs_nrun = 0;)
 
-    auto all_mine = [&](uint32_t want, const u32x2 (&g)[KR]) -> bool {
+    auto all_mine = [&](uint32_t want, const greg (&g)[GR]) -> bool {
         bool mine = true;
 #pragma unroll
-        for (int r = 0; r < KR; ++r) mine = mine && (vo[r] == kOobOffset || g[r].y == want);
+        for (int q = 0; q < GR; ++q) mine = mine && GT::is(g[q], want);
         return __builtin_amdgcn_ballot_w64(!mine) == 0ull;
     };
-    // Slow path of a wait: polls until all k granules of the row carry `want`; false if the wave gave up (status set).
+    // Slow path of a wait: polls until all granules of the row carry `want`; false if the wave gave up (status set).
     // Far from its turn (the row's version says how far) a wave sleeps in proportion and polls ONE granule; only the next
-    // toucher re-reads the whole row.
-    // (its loads are assembly with their own full waits as well: a compiler-tracked load here would make the compiler drain
-    // the queue where this path joins the straight-line one)
-    auto acquire_slow = [&](const i32x4 &rs, unsigned so, uint32_t want, u32x2 (&g)[KR]) -> bool {
+    // toucher re-reads the whole row.  (Its loads are assembly with their own full waits as well: a compiler-tracked load
+    // here would make the compiler drain the queue where this path joins the straight-line one.)
+    auto acquire_slow = [&](const i32x4 &rs, unsigned so, uint32_t want, greg (&g)[GR]) -> bool {
         uint32_t polls = 0;
         bool fresh = false;                                      // g is the prefetch of several triplets ago: its version says nothing yet
         for (;;) {
             // how far away is my turn?  (granule 0 of the row; a row in the middle of a rewrite reads as distance 0)
-            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)g[0].y) : 0u;
+            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(g[0])) : 0u;
             fresh = true;
             while ((int32_t)dist > 1) {
                 const uint32_t naps = dist < 16u ? dist : 16u;      // ~0.5 us per touch in front of me, capped
                 for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(20);
-                u32x2 one;
+                greg one[1];
                 const unsigned v1 = lane == 0 ? 0u : kOobOffset;
-                YUE_RING_LOAD(one, v1, rs, so);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(one) :: "memory");
-                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)one.y);
+                GT::load(one[0], v1, rs, so);
+                row_wait_all<1>(one);
+                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(one[0]));
                 if (++polls > a.spin_limit || (int32_t)dist < 0) break;
                 if ((polls & 63u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             }
             if ((int32_t)dist < 0 || ++polls > a.spin_limit) { if (lane == 0) atomicOr(a.status, (int32_t)dist < 0 ? 2u : 1u); return false; }
             if ((polls & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
 #pragma unroll
-            for (int r = 0; r < KR; ++r) YUE_RING_LOAD(g[r], vo[r], rs, so);
-            if constexpr (KR == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]) :: "memory");
-            else if constexpr (KR == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) :: "memory");
+            for (int q = 0; q < GR; ++q) GT::load(g[q], vo[q], rs, so);
+            row_wait_all<GR>(g);
             if (all_mine(want, g)) return true;
         }
     };
@@ -251,132 +274,134 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
         const int64_t e0 = a.run_ptr[run], e1 = a.run_ptr[run + 1];
         if (e1 <= e0) continue;
         const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
+        const unsigned len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
 
-        // headers of the first two groups, rows of the first group
-        int hi[2][G], hj[2][G];
-        uint32_t hwi[2][G], hwj[2][G];
-        auto load_header = [&](int which, int64_t base) {
-            const HeaderBlock<G> bi = *reinterpret_cast<const HeaderBlock<G> *>(evi + base);
-            const HeaderBlock<G> bj = *reinterpret_cast<const HeaderBlock<G> *>(evj + base);
-            const HeaderBlock<G> bwi = *reinterpret_cast<const HeaderBlock<G> *>(ordi + base);
-            const HeaderBlock<G> bwj = *reinterpret_cast<const HeaderBlock<G> *>(ordj + base);
-#pragma unroll
-            for (int s = 0; s < G; ++s) {
-                const bool ex = base + s < e1;
-                hi[which][s] = ex ? bi.w[s] : 0; hj[which][s] = ex ? bj.w[s] : -1;
-                hwi[which][s] = (uint32_t)bwi.w[s]; hwj[which][s] = (uint32_t)bwj.w[s];
-            }
-        };
-        auto no_header = [&](int which) {
-#pragma unroll
-            for (int s = 0; s < G; ++s) { hi[which][s] = 0; hj[which][s] = -1; hwi[which][s] = hwj[which][s] = 0u; }
-        };
-        u32x2 gi[G][KR], gj[G][KR];
-        // loads of one slot: 2 KR ring loads, real ones for an event with a negative, out-of-range dummies otherwise
-        auto fill = [&](int which, int s) {
-            const bool live = hj[which][s] >= 0;
-            const unsigned oi = live ? (unsigned)hi[which][s] * row_bytes : 0u, oj = live ? (unsigned)hj[which][s] * row_bytes : 0u;
-#pragma unroll
-            for (int r = 0; r < KR; ++r) {
-                const unsigned v = live ? vo[r] : v_oob;
-                YUE_RING_LOAD(gj[s][r], v, rq, oj); YUE_RING_LOAD(gi[s][r], v, rq, oi);
-            }
-        };
-        load_header(0, e0);
-#pragma unroll
-        for (int s = 0; s < G; ++s) fill(0, s);
-        if (e0 + G < e1) load_header(1, e0 + G); else no_header(1);
-
-        float p[KR];
+        gval p[GR];
         uint32_t pver = 0u;
+        i32x4 rp;
         if (PVER) {
             // user rows as granules, addressed through a descriptor based at the row (any number of users)
-            const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.Pv + (uint64_t)u * k, 0, (int)row_bytes, kRsrcFlags);
-            i32x4 rp;
-            { const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * k); rp.x = (int)(uint32_t)pa; rp.y = (int)((uint32_t)(pa >> 32) & 0xffffu); rp.z = (int)row_bytes; rp.w = kRsrcFlags; }
+            const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * (row_bytes / 4u));
+            rp.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)pa); rp.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xffffu));
+            rp.z = (int)row_bytes; rp.w = kRsrcFlags;
+            // v_readfirstlane has just written two words of the descriptor: a vector-memory instruction may read an SGPR a
+            // VALU instruction wrote only 5 wait states later, and the compiler does not see into the assembly below
+            asm volatile("s_nop 4" : "+s"(rp));
             pver = a.ord_u[run];
-            u32x2 g[KR];
+            greg g[GR];
 #pragma unroll
-            for (int r = 0; r < KR; ++r) g[r] = YUE_GLOAD(rsP, vo[r], 0u);
+            for (int q = 0; q < GR; ++q) GT::load(g[q], vo[q], rp, 0u);
+            row_wait_all<GR>(g);
             if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) { dead = true; break; }
 #pragma unroll
-            for (int r = 0; r < KR; ++r) p[r] = __builtin_bit_cast(float, g[r].x);
+            for (int q = 0; q < GR; ++q) p[q] = GT::value(g[q]);
         } else {
             const float *prow = a.P + (uint64_t)u * k;
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; p[r] = e < k ? prow[e] : 0.0f; }
+            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; p[q] = e < k ? prow[e] : 0.0f; }
         }
-        // (an empty statement that reads p: the compiler places ITS wait for the user row's loads here, not in front of every
-        // step's arithmetic, where it would drain the ring)
-#pragma unroll
-        for (int r = 0; r < KR; ++r) asm volatile("" : "+v"(p[r]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the ring is full: from here on the counted waits hold
 
-        for (int64_t base = e0; base < e1 && !dead; base += G) {
-#pragma unroll
-            for (int s = 0; s < G; ++s) {
-                YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter(); bool cs_waited = false;)
-                ring_wait<KR, (G - 1) * 4 * KR>(gi[s], gj[s]);
-                bool done = false;
-                if (hj[0][s] >= 0 && !dead) {                        // (wave-uniform) an event of the run with a negative
-                    const uint32_t wi = hwi[0][s], wj = hwj[0][s];
-                    const unsigned oi = (unsigned)hi[0][s] * row_bytes, oj = (unsigned)hj[0][s] * row_bytes;
-                    bool ok = true;
-                    if (!all_mine(wj, gj[s])) { ok = acquire_slow(rq, oj, wj, gj[s]); YUE_CS(cs_waited = true;) }
-                    if (ok && !all_mine(wi, gi[s])) { ok = acquire_slow(rq, oi, wi, gi[s]); YUE_CS(cs_waited = true;) }
-                    if (!ok) dead = true;
-                    else {
-                        float qi[KR], qj[KR];
-#pragma unroll
-                        for (int r = 0; r < KR; ++r) { qi[r] = __builtin_bit_cast(float, gi[s][r].x); qj[r] = __builtin_bit_cast(float, gj[s][r].x); }
-                        float ai = 0.0f, aj = 0.0f;
-#pragma unroll
-                        for (int r = 0; r < KR; ++r) { const float a1 = p[r] * qi[r]; ai = ai + a1; const float a2 = p[r] * qj[r]; aj = aj + a2; }
-                        const float x = wave_sum(ai) - wave_sum(aj);                 // BPR.py:50, fp32 margin
-                        const double xd = (double)x;
-                        double sg;
-                        if (__builtin_fabs(xd) <= 700.0) sg = chain_rcp(1.0 + chain_exp(-xd));     // qmath.py:115-116
-                        else sg = 1.0 / (1.0 + exp(-xd));
-                        const float c = (float)(a.lr * (1.0 - sg));
-#pragma unroll
-                        for (int r = 0; r < KR; ++r) {
-                            const Elem o = bpr_elem(p[r], qi[r], qj[r], c, a.ru, a.ri);
-                            p[r] = o.p2;
-                            u32x2 ni, nj;
-                            ni.x = __builtin_bit_cast(unsigned, o.qi2); ni.y = wi + 1u;
-                            nj.x = __builtin_bit_cast(unsigned, o.qj2); nj.y = wj + 1u;
-                            YUE_RING_STORE(ni, vo[r], rq, oi);                       // the positive's row first: the hotter of the two
-                            YUE_RING_STORE(nj, vo[r], rq, oj);
-                        }
-                        sv = (unsigned)lane == nsv ? sg : sv;
-                        if (++nsv == 64u) flush_logs();
-                        done = true;
-                    }
-                }
-                if (!done) {                                         // no event in this slot: the step's stores as dummies
-                    u32x2 z; z.x = 0u; z.y = 0u;
-#pragma unroll
-                    for (int r = 0; r < KR; ++r) { YUE_RING_STORE(z, v_oob, rq, 0u); YUE_RING_STORE(z, v_oob, rq, 0u); }
-                }
-                fill(1, s);                                          // refill the slot with the same slot of the next group
-                YUE_CS(if (done) { const unsigned long long dt = __builtin_readcyclecounter() - cs_t0; cs_steps += dt; if (cs_waited) { cs_slow += dt; ++cs_nslow; } else { cs_fast += dt; ++cs_nfast; } })
+        // The run in segments of 64 triplets (one segment for the usual run): the segment's headers sit in the lanes of four
+        // registers, the ring is filled at its start and drained at its end.
+        for (unsigned seg = 0; seg < len && !dead; seg += 64u) {
+            int hAi, hAj;
+            uint32_t hAwi, hAwj;
+            {
+                const bool ex = seg + (unsigned)lane < len;
+                const int64_t e = e0 + seg + (ex ? lane : 0);
+                hAi = evi[e]; hAj = evj[e]; hAwi = ordi[e]; hAwj = ordj[e];
+                if (!ex) { hAi = 0; hAj = -1; }
             }
+            greg gi[G][GR], gj[G][GR];
+            // loads of one slot: 2 GR ring loads, real ones for an event with a negative, out-of-range dummies otherwise
+            auto fill = [&](int s, int i_, int j_) {
+                const bool live = j_ >= 0;
+                const unsigned oi = live ? (unsigned)i_ * row_bytes : 0u, oj = live ? (unsigned)j_ * row_bytes : 0u;
 #pragma unroll
-            for (int s = 0; s < G; ++s) { hi[0][s] = hi[1][s]; hj[0][s] = hj[1][s]; hwi[0][s] = hwi[1][s]; hwj[0][s] = hwj[1][s]; }
-            if (base + 2 * G < e1) load_header(1, base + 2 * G); else no_header(1);
+                for (int q = 0; q < GR; ++q) {
+                    const unsigned v = live ? vo[q] : v_oob;
+                    GT::load(gj[s][q], v, rq, oj); GT::load(gi[s][q], v, rq, oi);
+                }
+            };
+            // (empty statements that read what the compiler's own loads above produced: the compiler places ITS waits for them
+            // here, not in front of every step's arithmetic, where they would drain the ring)
+#pragma unroll
+            for (int q = 0; q < GR; ++q) asm volatile("" : "+v"(p[q]));
+            asm volatile("" : "+v"(hAi), "+v"(hAj), "+v"(hAwi), "+v"(hAwj));
+#pragma unroll
+            for (int s = 0; s < G; ++s) fill(s, __builtin_amdgcn_readlane(hAi, s), __builtin_amdgcn_readlane(hAj, s));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring is full: from here on the counted waits hold
+
+            const unsigned seg_len = len - seg < 64u ? len - seg : 64u;
+            for (unsigned ol = 0; ol < seg_len && !dead; ol += G) {
+                const bool more = ol + G < 64u;                      // refills stay inside the segment
+#pragma unroll
+                for (int s = 0; s < G; ++s) {
+                    YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter(); bool cs_waited = false;)
+                    ring_wait<GR, (G - 1) * 4 * GR>(gi[s], gj[s]);
+                    const int ti = __builtin_amdgcn_readlane(hAi, ol + s), tj = __builtin_amdgcn_readlane(hAj, ol + s);
+                    bool done = false;
+                    if (tj >= 0 && !dead) {                          // (wave-uniform) an event of the run with a negative
+                        const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, ol + s), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, ol + s);
+                        const unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)tj * row_bytes;
+                        bool ok = true;
+                        if (!all_mine(wj, gj[s])) { ok = acquire_slow(rq, oj, wj, gj[s]); YUE_CS(cs_waited = true;) }
+                        if (ok && !all_mine(wi, gi[s])) { ok = acquire_slow(rq, oi, wi, gi[s]); YUE_CS(cs_waited = true;) }
+                        if (!ok) dead = true;
+                        else {
+                            gval qi[GR], qj[GR];
+#pragma unroll
+                            for (int q = 0; q < GR; ++q) { qi[q] = GT::value(gi[s][q]); qj[q] = GT::value(gj[s][q]); }
+                            // per-lane partials in element order 64 r + l, r ascending (oracle/bpr_oracle.c: dot64)
+                            float ai = 0.0f, aj = 0.0f;
+#pragma unroll
+                            for (int q = 0; q < GR; ++q) { const gval mi = p[q] * qi[q], mj = p[q] * qj[q]; ai = ai + mi; aj = aj + mj; }
+                            const float x = wave_sum(ai) - wave_sum(aj);             // BPR.py:50, fp32 margin
+                            const double xd = (double)x;
+                            double sg;
+                            if (__builtin_fabs(xd) <= 700.0) sg = chain_rcp(1.0 + chain_exp(-xd)); // qmath.py:115-116
+                            else sg = 1.0 / (1.0 + exp(-xd));
+                            const float c = (float)(a.lr * (1.0 - sg));
+#pragma unroll
+                            for (int q = 0; q < GR; ++q) {
+                                // BPR.py:51-57 (as bpr_elem)
+                                const gval d = qi[q] - qj[q];
+                                const gval td = c * d;
+                                const gval p1 = p[q] + td;
+                                const gval tq = c * p1;
+                                const gval qi1 = qi[q] + tq, qj1 = qj[q] - tq;
+                                const gval rpp = a.ru * p1, ra = a.ri * qi1, rb = a.ri * qj1;
+                                p[q] = p1 - rpp;
+                                GT::store(GT::make(qi1 - ra, wi + 1u), vo[q], rq, oi);   // the positive's row first: the hotter of the two
+                                GT::store(GT::make(qj1 - rb, wj + 1u), vo[q], rq, oj);
+                            }
+                            sv = (unsigned)lane == nsv ? sg : sv;
+                            if (++nsv == 64u) flush_logs();
+                            done = true;
+                        }
+                    }
+                    if (!done) {                                     // no event in this slot: the step's stores as dummies
+                        greg z = GT::make(0.0f, 0u);
+#pragma unroll
+                        for (int q = 0; q < GR; ++q) { GT::store(z, v_oob, rq, 0u); GT::store(z, v_oob, rq, 0u); }
+                    }
+                    // refill with the same slot of the next group (dummies past the segment's last group)
+                    fill(s, more ? __builtin_amdgcn_readlane(hAi, (ol + G + s) & 63u) : 0, more ? __builtin_amdgcn_readlane(hAj, (ol + G + s) & 63u) : -1);
+                    YUE_CS(if (done) { const unsigned long long dt = __builtin_readcyclecounter() - cs_t0; cs_steps += dt; if (cs_waited) { cs_slow += dt; ++cs_nslow; } else { cs_fast += dt; ++cs_nfast; } })
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing of this segment's ring is in flight when the next one refills it
         }
         if (dead) break;
 
         if (PVER) {
-            const auto rsP = __builtin_amdgcn_make_buffer_rsrc(a.Pv + (uint64_t)u * k, 0, (int)row_bytes, kRsrcFlags);
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { u32x2 g; g.x = __builtin_bit_cast(unsigned, p[r]); g.y = pver + 1u; YUE_GSTORE(g, rsP, vo[r], 0u); }
+            for (int q = 0; q < GR; ++q) GT::store(GT::make(p[q], pver + 1u), vo[q], rp, 0u);
         } else {
             float *prow = a.P + (uint64_t)u * k;
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; if (e < k) prow[e] = p[r]; }
+            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; if (e < k) prow[e] = p[q]; }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing of this run's ring is in flight when the next run refills it
         YUE_CS(cs_run += __builtin_readcyclecounter() - cs_r0 - cs_steps; ++cs_nrun;)
     }
     YUE_CS(if (lane == 0) { atomicAdd(a.stats + 0, cs_fast); atomicAdd(a.stats + 1, cs_nfast); atomicAdd(a.stats + 2, cs_slow); atomicAdd(a.stats + 3, cs_nslow); atomicAdd(a.stats + 4, cs_run); atomicAdd(a.stats + 5, cs_nrun); })

@@ -124,7 +124,7 @@ struct yue_ctx {
     DevBuf<int64_t> ch_run_ptr, d_ev_ptr;
     DevBuf<int32_t> ch_run_u;
     DevBuf<unsigned char> ch_tmp;
-    DevBuf<uint2> ch_Qv, ch_Pv;
+    DevBuf<unsigned> ch_Qv, ch_Pv;
     DevBuf<unsigned long long> ch_ctl;   // [0] run claim counter, [1] validation flags, [2] wait status
     DevBuf<unsigned long long> ch_stats; // diagnostic build (make chainstats) only
     bool d_ev_ptr_valid = false;
