@@ -9,10 +9,20 @@ scaling), users are replicated, user-factor differences are all-reduced over RCC
 library; yue_amd/dist.py (standard-library TCP, no torch in the ranks) only ships the RCCL id, runs the
 barriers and takes the max-over-ranks time.
 
+For N > 1 the default workload is one GPU's share of BASELINE config 4 per rank (`c4shard`: 10M replicated users, a
+125K-item shard and 60M events per rank -- at N = 8 exactly config 4; `--workload c3` keeps config 3 per rank), and the
+line carries `comm` (all-reduce bytes and collectives per epoch and rank, the time the compute stream waited for the
+collective stream, RCCL version and rank count).
+
 One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the library's stream),
-`cpu_baseline` (oracle/ timed on one host core, N=1 only) and, at N=1, `secondary.c5`: the top-N scoring
-path (BASELINE config 5 on a 65,536-user slice of the same users, the factors the timed epochs left) with
-its own roofline (MFMA) and CPU baseline.
+`cpu_baseline` (oracle/ timed on one host core, N=1 only) and, at N=1:
+  `config.deviation_vs_sequential`  how far ONE epoch of the timed S-round semantics lands from the reference's sequential
+                  loop run on the same factors and negatives (the exact device path, itself checked against the oracle);
+  `secondary.exact`  the EXACT path (recommender/cf/BPR.py:40-62 semantics, chain_kernels.hpp) on config 3 and config 2:
+                  triplets/s of a whole epoch, dependency depth of the stream, and the same stream through yue_bpr_replay
+                  from host arrays;
+  `secondary.c5`  the top-N scoring path (BASELINE config 5: all 1M users x 200K items, the factors the timed epochs left)
+                  with its own roofline (MFMA) and CPU baseline.
 """
 import argparse
 import json
@@ -78,6 +88,7 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
     t0 = time.perf_counter()
     orc.bpr_sequential(P, Q, ev_u[:S], data['ev_i'][:S], j_first[:S], LR, REG_U, REG_I)
     dt = time.perf_counter() - t0
+    cpu_baseline.prefix = (S, P, Q)                       # the exact device path is checked against this state (secondary_exact)
     # NumPy loop: ~1e5 triplets/s
     Sn = min(len(j_first), 300000)
     P, Q = P0.copy(), Q0.copy()
@@ -165,9 +176,9 @@ def scoring_cpu_baseline(dev, data, users, ids, N, n, budget_s):
                       % (S, n, cdt, _cpu_name())}
 
 
-def secondary_scoring(dev, data, m, n, k, no_cpu):
-    """BASELINE config 5 on the first 65,536 users (all items, N = 20, training items masked) with the factors on the device."""
-    N, nu, steps = 20, min(m, 65536), 3
+def secondary_scoring(dev, data, m, n, k, no_cpu, state):
+    """BASELINE config 5 at its stated size: all users x all items, N = 20, training items masked, with the factors on the device."""
+    N, nu, steps = 20, m, 3
     users = np.arange(nu, dtype=np.int32)
     dev.topn_scan(users, N)
     t0 = time.perf_counter()
@@ -182,13 +193,104 @@ def secondary_scoring(dev, data, m, n, k, no_cpu):
     peak = MFMA_BF16_PEAK if used_bf16 else MFMA_F32_PEAK
     return {'metric': 'top-%d scoring users/sec (P.Q^T + overwrite-scan selection), k=%d' % (N, k), 'value': nu * steps / dt, 'unit': 'users/s',
             'steps': steps, 'ms_per_step': 1e3 * dt / steps, 'dtype': 'bf16 pre-filter + f32 exact re-score' if used_bf16 else 'f32',
-            'config': {'workload': 'C5 slice: %d of the %d users x %d items, k=%d, N=%d, training items masked, factors as the timed epochs left them; '
-                                   'host copies of ids/scores included in value' % (nu, m, n, k, N),
+            'config': {'workload': 'C5: all %d users x %d items, k=%d, N=%d, training items masked; factors: %s; '
+                                   'host copies of ids/scores included in value' % (m, n, k, N, state),
                        'state_machine_events_per_user': events / nu, 'exact_rescores_per_user': rescored / nu,
                        'tiles_scored_fraction': done / max(1, total)},
             'roofline': {'bound': 'mfma', 'kernel': scan_kernel_label(dev, k) if used_bf16 else 'k_topn_scan (f32 MFMA)', 'achieved': ach / 1e12,
                          'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel_ms_per_scan': kms / steps, 'traffic': None},
             'cpu_baseline': None if no_cpu else scoring_cpu_baseline(dev, data, users, ids, N, n, 4.0)}
+
+
+
+def _rms(a):
+    a = a.astype(np.float64, copy=False).ravel()
+    return float(np.sqrt(np.dot(a, a) / a.size))
+
+
+def deviation_vs_sequential(dev, P0, Q0, seed, W, E):
+    """One epoch from (P0, Q0) on the device sampler's epoch-0 negatives, twice: with the reference's exact sequential semantics
+    (option epoch_exact: chain_kernels.hpp, bit-checked against oracle/ by tests/test_gpu_exact.py and by secondary.exact below)
+    and with the S-round semantics at round size W.  Returns the distance between the two end points."""
+    dev.set_factors(P0, Q0)
+    dev.set_option('epoch_exact', 1)
+    t0 = time.perf_counter()
+    nll_e = dev.bpr_epoch(seed, 0, 0, LR, REG_U, REG_I)[0]
+    t_exact = time.perf_counter() - t0
+    dev.set_option('epoch_exact', 0)
+    Pe, Qe = dev.get_factors()
+    dev.set_factors(P0, Q0)
+    nll_r = dev.bpr_epoch(seed, 0, W, LR, REG_U, REG_I)[0]
+    Pr, Qr = dev.get_factors()
+    out = {'round_events': W,
+           'what': 'one epoch from the initial factors on the same negatives: S-round end point against the exact sequential loop on the device',
+           'loss_rel': (nll_r - nll_e) / nll_e,
+           'nll_per_triplet': {'sequential': nll_e / E, 's_round': nll_r / E},
+           'rms_distance_over_rms_movement': {'P': _rms(Pr - Pe) / _rms(Pe - P0), 'Q': _rms(Qr - Qe) / _rms(Qe - Q0)},
+           'normwise_rel': {'P': float(np.abs(Pr - Pe).max() / np.abs(Pe).max()), 'Q': float(np.abs(Qr - Qe).max() / np.abs(Qe).max())}}
+    return out, (nll_e, t_exact)
+
+
+def exact_line(dev, name, data, P0, Q0, seed, k, steps, no_cpu, prefix=None):
+    """The exact path on one workload: `steps` whole epochs through yue_bpr_epoch(option epoch_exact) -- sampler pass, row
+    ordinals (device sort), granule copies and the dataflow launch all inside the timed call -- and the first epoch's stream
+    once more through yue_bpr_replay from host arrays (upload of 12 bytes per triplet inside the timed call)."""
+    m, n = P0.shape[0], Q0.shape[0]
+    E = int(data['ev_ptr'][-1])
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    j0 = dev.sample_negatives(seed, 0)
+    out = {'workload': name, 'triplets_per_epoch': E}
+    check = None
+    if prefix is not None:
+        # exactness on the bench workload itself: the first S triplets of epoch 0 against the CPU oracle's state after them
+        S, Ps, Qs = prefix
+        dev.bpr_replay(ev_u[:S], data['ev_i'][:S], j0[:S], LR, REG_U, REG_I)
+        P, Q = dev.get_factors()
+        check = {'triplets': S, 'rel_err_P': float(np.abs(P - Ps).max() / np.abs(Ps).max()), 'rel_err_Q': float(np.abs(Q - Qs).max() / np.abs(Qs).max()),
+                 'against': 'oracle/bpr_oracle.c: orc_bpr_sequential on the same prefix (the cpu_baseline run)'}
+        if max(check['rel_err_P'], check['rel_err_Q']) > 1e-5:
+            sys.exit('exact path differs from the oracle: %r' % check)
+        dev.set_factors(P0, Q0)
+    dev.set_option('epoch_exact', 1)
+    dev.bpr_epoch(seed, 0, 0, LR, REG_U, REG_I)                      # warm-up (allocations of the pre-pass)
+    dev.sync()
+    t0 = time.perf_counter()
+    for ep in range(1, steps + 1):
+        nll = dev.bpr_epoch(seed, ep, 0, LR, REG_U, REG_I)[0]
+    dt = (time.perf_counter() - t0) / steps
+    dev.set_option('epoch_exact', 0)
+    runs, waves = dev.get_option('chain_last_runs'), dev.get_option('chain_last_waves')
+    dev.set_factors(P0, Q0)
+    t0 = time.perf_counter()
+    dev.bpr_replay(ev_u, data['ev_i'], j0, LR, REG_U, REG_I)
+    dt_replay = time.perf_counter() - t0
+    out.update({'value': E / dt, 'unit': 'triplets/s', 'ms_per_epoch': 1e3 * dt, 'steps': steps, 'final_nll_per_triplet': nll / E,
+                'runs': runs, 'waves': waves,
+                'replay_from_host_arrays': {'value': E / dt_replay, 'unit': 'triplets/s', 'ms': 1e3 * dt_replay,
+                                            'what': 'yue_bpr_replay(u, i, j) of epoch 0: upload of the stream, runs and ordinals on the device, user rows versioned per run'},
+                'checked_against_oracle': check})
+    if not no_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        depth, row_max = oracle.Oracle().dependency_depth(ev_u, data['ev_i'], j0, m, n)
+        out['dependency'] = {'depth': depth, 'hottest_row_touches': row_max, 'us_per_dependent_step': 1e6 * dt / depth,
+                             'what': 'longest chain of dependent triplets of the epoch-0 stream (a triplet depends on the latest earlier one sharing P[u], Q[i] or Q[j]): '
+                                     'no schedule of the exact loop takes fewer steps; the levelled replay of round 1 (option replay_levels) needs this many LAUNCHES; '
+                                     'computed on the host by oracle/ outside the timed region (%.1f s)' % (time.perf_counter() - t0)}
+    return out
+
+
+def secondary_exact(dev, data, P0, Q0, seed, k, no_cpu):
+    out = {'metric': 'BPR triplet-updates/sec with the reference\'s exact sequential semantics (recommender/cf/BPR.py:40-62)',
+           'kernel': 'k_bpr_chain (one dataflow launch per epoch: a wave per user run, item rows as versioned 8-byte granules, row ordinals from a device sort)',
+           'c3': exact_line(dev, 'C3: 1000000 users x 200000 items, k=128, 50 events/user', data, P0, Q0, seed, k, 2, no_cpu, getattr(cpu_baseline, 'prefix', None))}
+    m2, n2, d2, k2 = WORKLOADS['c2']
+    data2 = synth.make_arrays(m2, n2, d2, seed=20260001)
+    P2, Q2 = synth.init_factors(m2, n2, k2, 20260002)
+    out['c2'] = exact_line(dev, 'C2: 100000 users x 50000 items, k=64, 50 events/user', data2, P2, Q2, seed, k2, 2, no_cpu)
+    return out
 
 
 def bench_scoring(args, cp):
@@ -315,7 +417,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS), help='default: c3 on one GPU, c4shard per rank on several')
     ap.add_argument('--round-events', type=int, default=0, help='events per S-round; 0 = the library\'s default for this device and problem (yue_default_round_events)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the scoring line (secondary.c5) of the default run')
@@ -332,6 +434,8 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
         args.gpus = world
 
+    if args.workload is None:
+        args.workload = 'c3' if world == 1 else 'c4shard'
     if args.workload.startswith('c5'):
         return bench_scoring(args, cp)
     if args.workload == 'fism':
@@ -385,6 +489,7 @@ def main():
     dt = cp.reduce_max(dt)
     k_ms, k_launches, k_triplets = dev.get_kernel_timing()
     dev.set_kernel_timing(0)
+    comm = dev.comm_stats()
     if not np.isfinite(nll):
         sys.exit('loss is not finite')
 
@@ -413,11 +518,20 @@ def main():
                                    'per epoch <= ms_per_step by construction; the kernel-only averages are in the rocprofv3 summary under profiles/',
                          'traffic': traffic[0] if traffic else None, 'traffic_source': traffic[1] if traffic else None},
         }
+        if world > 1 or args.force_comm:
+            out['comm'] = {'allreduce_bytes_per_epoch_per_rank': comm['allreduce_bytes'], 'collectives_per_epoch': comm['collectives'],
+                           'compute_stream_wait_ms_last_epoch': comm['wait_ms'], 'nranks_rccl': comm['nranks'], 'rccl_version': comm['rccl_version'],
+                           'what': 'ncclAllReduce (fp32 sum, in place) of the user-factor differences of a group of user blocks, on a second HIP stream beside the next '
+                                   'group\'s rounds; wait = end of the last group\'s all-reduce + apply minus end of the last round launch (HIP events)'}
         if world == 1 and not args.no_cpu_baseline:
             j0 = dev.sample_negatives(seed, 0)
             out['cpu_baseline'] = cpu_baseline(data, P0, Q0, j0, k)
         if world == 1 and not args.no_secondary and not args.force_comm and args.workload == 'c3':
-            out['secondary'] = {'c5': secondary_scoring(dev, data, m, n, k, args.no_cpu_baseline)}
+            out['secondary'] = {'c5': secondary_scoring(dev, data, m, n, k, args.no_cpu_baseline,
+                                                        'as the %d S-round epochs of this run (warm-up + timed) left them' % (args.warmup + args.steps))}
+            dev_out, _ = deviation_vs_sequential(dev, P0, Q0, seed, args.round_events, E)
+            out['config']['deviation_vs_sequential'] = dev_out
+            out['secondary']['exact'] = secondary_exact(dev, data, P0, Q0, seed, k, args.no_cpu_baseline)
         print(json.dumps(out))
     dev.close()
     cp.close()

@@ -222,6 +222,11 @@ int yue_comm_unique_id(void *id128_out);
 int yue_comm_init(yue_ctx *ctx, const void *id128, int rank, int nranks);
 /* Sum a double across ranks (loss terms); identity without a communicator. */
 int yue_allreduce_f64(yue_ctx *ctx, double *vals, int count);
+/* The last yue_bpr_epoch on a communicator: bytes this rank handed to ncclAllReduce (user-factor differences, fp32), the
+ * number of collectives, the time the compute stream had to wait for the second stream (all-reduce + apply of the last
+ * group) after its own last round launch had finished (HIP events), the communicator's rank count as RCCL reports it and
+ * the RCCL version (ncclGetVersion).  Zeros / 1 without a communicator. */
+int yue_get_comm_stats(yue_ctx *ctx, double *allreduce_bytes, int64_t *collectives, double *wait_ms, int *nranks, int *rccl_version);
 
 #ifdef __cplusplus
 }

@@ -228,6 +228,32 @@ double orc_bpr_sequential(float *P, float *Q, int k, const int32_t *u, const int
     return nll;
 }
 
+/* Dependency depth of a triplet stream under the sequential semantics of BPR.py:42-58: a triplet depends on the latest
+ * earlier triplet that touches P[u], Q[i] or Q[j]; the depth is the longest chain of dependent triplets -- the number of
+ * steps no schedule of the exact loop can go below (measurement aid of bench.py / the tests, not part of the path).
+ * row_max_out (may be NULL): the largest number of touches of one item row. */
+int64_t orc_dependency_depth(const int32_t *u, const int32_t *i, const int32_t *j, int64_t T, int64_t m, int64_t n, int64_t *row_max_out) {
+    int32_t *lp = (int32_t *)calloc((size_t)m, sizeof(int32_t)), *lq = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    int32_t *cq = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    int32_t depth = 0, row_max = 0;
+    if (!lp || !lq || !cq) { free(lp); free(lq); free(cq); return -1; }
+    for (int64_t t = 0; t < T; ++t) {
+        if (j[t] < 0) continue;
+        int32_t l = lp[u[t]];
+        if (lq[i[t]] > l) l = lq[i[t]];
+        if (lq[j[t]] > l) l = lq[j[t]];
+        ++l;
+        lp[u[t]] = lq[i[t]] = lq[j[t]] = l;
+        if (l > depth) depth = l;
+        if (++cq[i[t]] > row_max) row_max = cq[i[t]];
+        if (++cq[j[t]] > row_max) row_max = cq[j[t]];
+    }
+    if (row_max_out) *row_max_out = row_max;
+    free(lp); free(lq); free(cq);
+    return depth;
+}
+
+
 /*
  * Timing baseline only (bench.py cpu_baseline): the same loop run Hogwild-style by
  * `threads` threads, each over a contiguous slice of the triplet stream, racing on shared rows.

@@ -35,6 +35,7 @@ class Oracle(object):
         L.orc_sumsq.restype = C.c_double
         L.orc_bpr_round_deltas.restype = C.c_double
         L.orc_topn_scan.restype = C.c_int
+        L.orc_dependency_depth.restype = C.c_int64
 
     # -- samplers -------------------------------------------------------------
     def sample_python(self, seed, epochs, ev_u, n, indptr, indices, want_draws=False):
@@ -73,6 +74,13 @@ class Oracle(object):
         u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
         return self.lib.orc_bpr_hogwild(_p(P, C.c_float), _p(Q, C.c_float), C.c_int(P.shape[1]), _p(u, C.c_int32), _p(i, C.c_int32),
                                         _p(j, C.c_int32), C.c_int64(len(u)), C.c_double(lr), C.c_double(regU), C.c_double(regI), C.c_int(threads))
+
+    def dependency_depth(self, u, i, j, m, n):
+        """(longest chain of dependent triplets, touches of the hottest item row) of a stream under sequential semantics."""
+        u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
+        row_max = C.c_int64()
+        depth = self.lib.orc_dependency_depth(_p(u, C.c_int32), _p(i, C.c_int32), _p(j, C.c_int32), C.c_int64(len(u)), C.c_int64(m), C.c_int64(n), C.byref(row_max))
+        return int(depth), int(row_max.value)
 
     def bpr_rounds(self, P, Q, u, i, j, round_ptr, lr, regU, regI):
         assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous

@@ -22,7 +22,7 @@ SYMBOLS = ['yue_last_error', 'yue_version', 'yue_ctx_create', 'yue_ctx_destroy',
            'yue_set_factors', 'yue_get_factors', 'yue_set_interactions', 'yue_bpr_replay',
            'yue_bpr_rounds', 'yue_bpr_epoch', 'yue_cune_steps', 'yue_adam_reset', 'yue_adam_step', 'yue_sample_negatives', 'yue_sumsq', 'yue_scores',
            'yue_topn_scan', 'yue_set_kernel_timing', 'yue_get_kernel_timing', 'yue_get_scan_stats', 'yue_get_scan_work', 'yue_set_option', 'yue_get_option',
-           'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64',
+           'yue_comm_unique_id', 'yue_comm_init', 'yue_allreduce_f64', 'yue_get_comm_stats',
            'yue_default_round_events', 'yue_epoch_plan',
            'yue_fism_set_model', 'yue_fism_get_model', 'yue_fism_epoch', 'yue_fism_rounds', 'yue_fism_scores', 'yue_fism_topn_scan']
 
@@ -334,6 +334,12 @@ class Device(object):
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._chk(self._lib.yue_comm_init(self._ctx, buf, C.c_int(rank), C.c_int(nranks)))
+
+    def comm_stats(self):
+        """Last bpr_epoch on a communicator: dict(allreduce_bytes, collectives, wait_ms, nranks, rccl_version)."""
+        b, n, w, r, v = C.c_double(), C.c_int64(), C.c_double(), C.c_int(), C.c_int()
+        self._chk(self._lib.yue_get_comm_stats(self._ctx, C.byref(b), C.byref(n), C.byref(w), C.byref(r), C.byref(v)))
+        return {'allreduce_bytes': b.value, 'collectives': n.value, 'wait_ms': w.value, 'nranks': r.value, 'rccl_version': v.value}
 
     def allreduce_f64(self, vals):
         arr = (C.c_double * len(vals))(*vals)

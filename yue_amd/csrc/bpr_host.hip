@@ -609,17 +609,31 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         }
         HIPCHK(hipEventRecord(c->ev_rounds, c->stream));
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0));
+        c->comm_collectives += 1;
+        c->comm_bytes += (double)count * sizeof(float);
         if (const int rcr = yue_host::reduce_user_block(c, first, count, c->comm_stream)) return rcr;
         hipLaunchKernelGGL(yue::k_apply_range, grid, dim3(256), 0, c->comm_stream, c->P.p, c->dP.p, first, count);
         return YUE_OK;
     };
+    c->comm_collectives = 0; c->comm_bytes = 0.0; c->comm_wait_ms = 0.0;
     if ((rc = run_rounds(c, a, bounds, 0, after, meta_path_fits(c)))) { reset_round_state(c); return rc; }
     // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
+    if (c->comm) {       // how long the compute stream has to wait for the last group's all-reduce + apply
+        HIPCHK(hipEventRecord(c->ev_t_rounds, c->stream));
+        HIPCHK(hipEventRecord(c->ev_t_comm, c->comm_stream));
+    }
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
-    return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
+    if ((rc = read_scalars(c, nll_out, sumsqP_out, sumsqQ_out))) return rc;
+    if (c->comm) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(c->ev_t_comm));
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_t_rounds, c->ev_t_comm));
+        c->comm_wait_ms = ms > 0.f ? ms : 0.0;
+    }
+    return YUE_OK;
 }
 
 int yue_epoch_plan(int64_t m, int k, int64_t round_events, double events_total, int nranks,

@@ -44,6 +44,20 @@ int yue_comm_init(yue_ctx *c, const void *id128, int rank, int nranks) {
     std::memcpy(&id, id128, sizeof id);
     NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
     c->rank = rank; c->nranks = nranks;
+    int ver = 0, cnt = 0;
+    NCCLCHK(ncclGetVersion(&ver));
+    NCCLCHK(ncclCommCount(c->comm, &cnt));
+    c->comm_version = ver; c->comm_nranks_reported = cnt;
+    return YUE_OK;
+}
+
+int yue_get_comm_stats(yue_ctx *c, double *allreduce_bytes, int64_t *collectives, double *wait_ms, int *nranks, int *rccl_version) {
+    if (!c) return fail(YUE_ERR_ARG, "null context");
+    if (allreduce_bytes) *allreduce_bytes = c->comm_bytes;
+    if (collectives) *collectives = c->comm_collectives;
+    if (wait_ms) *wait_ms = c->comm_wait_ms;
+    if (nranks) *nranks = c->comm ? c->comm_nranks_reported : 1;
+    if (rccl_version) *rccl_version = c->comm_version;
     return YUE_OK;
 }
 

@@ -27,6 +27,8 @@ int yue_ctx_create(int device, yue_ctx **out) {
         HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_rounds, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&c->ev_t_rounds));
+        HIPCHK(hipEventCreate(&c->ev_t_comm));
         HIPCHK(hipEventCreate(&c->ev_scan0));
         HIPCHK(hipEventCreate(&c->ev_scan1));
         HIPCHK(c->scal.resize(yue_host::kNllSlotsHost + 8));
@@ -47,6 +49,8 @@ int yue_ctx_destroy(yue_ctx *c) {
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->ev_rounds) (void)hipEventDestroy(c->ev_rounds);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    if (c->ev_t_rounds) (void)hipEventDestroy(c->ev_t_rounds);
+    if (c->ev_t_comm) (void)hipEventDestroy(c->ev_t_comm);
     if (c->ev_scan0) (void)hipEventDestroy(c->ev_scan0);
     if (c->ev_scan1) (void)hipEventDestroy(c->ev_scan1);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

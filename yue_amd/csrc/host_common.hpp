@@ -138,6 +138,11 @@ struct yue_ctx {
     int rank = 0, nranks = 1;
     hipStream_t comm_stream = nullptr;   // (all-reduce +) user-row apply of yue_bpr_epoch run here, beside the next rounds
     hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
+    hipEvent_t ev_t_rounds = nullptr, ev_t_comm = nullptr;   // timing pair of the last epoch on a communicator: end of its round launches / end of its last apply
+    // communicator statistics of the last yue_bpr_epoch (yue_get_comm_stats)
+    int64_t comm_collectives = 0;
+    double comm_bytes = 0.0, comm_wait_ms = 0.0;
+    int comm_version = 0, comm_nranks_reported = 0;
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr;      // brackets of the scoring kernel (yue_get_scan_stats)
 };
 

@@ -31,7 +31,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     if (nu == 0) return YUE_OK;
     HIPCHK(hipSetDevice(c->device));
     for (int64_t t = 0; t < nu; ++t) if (users[t] < 0 || users[t] >= c->m) return fail(YUE_ERR_ARG, "yue_topn_scan: user id out of range");
-    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4)); HIPCHK(c->s_work.resize(1));
+    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4)); HIPCHK(c->s_work.resize(4));
     HIPCHK(hipMemcpyAsync(c->s_users.p, users, nu * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     yue::ScanArgs sa{};
     sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
@@ -53,7 +53,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
         sa.mask_ptr = c->indptr.p; sa.mask_idx = c->indices.p; sa.mask_by_user = 1;
     }
     HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->s_work.p, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->s_work.p, 0, 4 * sizeof(unsigned long long), c->stream));
     sa.work = c->s_work.p;
     const int64_t ntile = (c->n + 31) / 32;
     HIPCHK(c->s_norms.resize(2 * ntile));
@@ -72,15 +72,15 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipMemcpyAsync(out_ids, c->s_ids.p, nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out_scores, c->s_scores.p, nu * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(flags, c->s_flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
-    unsigned long long work = 0;
-    HIPCHK(hipMemcpyAsync(&work, c->s_work.p, sizeof work, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long work[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(work, c->s_work.p, sizeof work, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, t0, t1));
     c->scan_ms = ms;
-    c->scan_events = flags[1];
-    c->scan_rescored = flags[2];
-    c->scan_tiles_done = (int64_t)work;
+    c->scan_events = (int64_t)work[1];
+    c->scan_rescored = (int64_t)work[2];
+    c->scan_tiles_done = (int64_t)work[0];
     c->scan_tiles_total = ((nu + 31) / 32) * ntile;
     if (flags[0]) return fail(YUE_ERR_FEW_ITEMS, "a user has fewer than N candidate items (the reference raises IndexError, base/IterativeRecommender.py:126)");
     return YUE_OK;

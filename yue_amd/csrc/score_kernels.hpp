@@ -35,8 +35,9 @@ struct ScanArgs {
     int mask_by_user;      // 1: mask row = user id (training CSR); 0: mask row = position in users[]
     int32_t *out_ids;
     float *out_scores;
-    int32_t *flags;        // [0] some user had < N candidates, [1] state-machine events, [2] exact re-scores (bf16 path)
-    unsigned long long *work; // [0] 32-user x 32-item tiles actually scored (the bf16 kernel skips tiles that cannot matter)
+    int32_t *flags;        // [0] some user had < N candidates
+    unsigned long long *work; // [0] 32-user x 32-item tiles actually scored (the bf16 kernel skips tiles that cannot matter),
+                              // [1] state-machine events, [2] exact re-scores (bf16 path) -- 64-bit: 1.6e9 re-scores on a full config-5 scan
     const float *tile_norm_max; // max ||Q[i]||_2 over each tile of 32 items (bf16 pre-filter margin); unused by the f32 kernel
     const float *tile_norm_sufmax; // max of tile_norm_max over this and all later tiles (early exit of the bf16 kernel)
     int true_topn;             // 0: the reference's overwrite-scan (default); 1: a real top-N (ties: lower id first)
@@ -98,14 +99,14 @@ __device__ __forceinline__ void scan_push(ScanState &S, int N, float s, int32_t 
     if (true_topn) scan_push_t<true>(S, N, s, item); else scan_push_t<false>(S, N, s, item);
 }
 
-__device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *flags) {
+__device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *flags, unsigned long long *work) {
     if (S.cnt < N) {
         atomicOr(flags, 1);
         for (int q = 0; q < N; ++q) { S.g_sc[q] = -INFINITY; S.g_id[q] = -1; }
     } else {
         for (int q = 0; q < N; ++q) { S.g_sc[q] = S.st_a[q]; S.g_id[q] = S.st_id[q]; }
     }
-    atomicAdd(flags + 1, S.events);
+    atomicAdd(work + 1, (unsigned long long)S.events);
 }
 
 // max ||Q[i]||_2 over each tile of 32 consecutive items: one wave per tile, lane pair (r, h) sums half
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
         __syncthreads();
     }
 
-    if (h == 0 && uvalid) scan_finish(S, N, a.flags);
+    if (h == 0 && uvalid) scan_finish(S, N, a.flags, a.work);
     if (lane == 0) atomicAdd(a.work, (unsigned long long)ntiles);
 }
 
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
         }
     }
 
-    if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags, a.work); atomicAdd(a.work + 2, (unsigned long long)rescored); }
     if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
 }
 
@@ -765,7 +766,7 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
         }
     }
 
-    if (h == 0 && uvalid) { scan_finish(S, N, a.flags); atomicAdd(a.flags + 2, rescored); }
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags, a.work); atomicAdd(a.work + 2, (unsigned long long)rescored); }
     if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
 }
 

@@ -124,3 +124,14 @@ def write_csr(path, m, n, d, d_test=6, seed=20260001):
     tp, ti = make_test_arrays(m, n, d, d_test, data['indptr'], data['indices'], seed=seed)
     save_csr(path, m, n, data['ev_ptr'], data['ev_i'], tp, ti)
     return data, tp, ti
+
+
+if __name__ == '__main__':
+    # python -m yue_amd.synth [path] [users] [items] [events per user]: the seeded text log the shipped config/*.conf read
+    import os
+    import sys
+    path = sys.argv[1] if len(sys.argv) > 1 else './dataset/log.txt'
+    m, n, d = (int(x) for x in (sys.argv[2:5] + ['1000', '1000', '20'][len(sys.argv[2:5]):]))
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    write_text_log(path, m, n, d)
+    print('wrote %s: %d users x %d items, %d events per user' % (path, m, n, d))
