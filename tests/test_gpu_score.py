@@ -205,3 +205,42 @@ def test_full_size_scan_properties(dev, orc):
     sub = slice(0, 24)
     oid, osc, _ = orc.topn_scan(P, Q, users[sub], N, *mask_rows(indptr, indices.reshape(-1).astype(np.int32), users[sub]))
     assert np.array_equal(ids[sub], oid) and np.array_equal(sc[sub], osc)
+
+
+def test_config5_at_its_stated_size(orc):
+    """BASELINE config 5 in full: 1M users x 200K items, k = 128, top-20, training items masked (the synthetic interactions and
+    factors of bench.py --workload c5).  Size-independent properties for ALL users -- ids in range, scores non-increasing, no
+    training item listed -- and, for sampled users, slot 0 = the arg-max of predict() over the candidates, listed scores =
+    predict()[ids] and the whole list equal to the oracle's."""
+    from yue_amd import synth
+    from yue_amd._shim import Device
+    m, n, d, k, N = 1000000, 200000, 50, 128, 20
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P, Q = synth.init_factors(m, n, k, 20260002)
+    dev = Device(0, raise_errors=True)
+    try:
+        dev.set_factors(P, Q)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        users = np.arange(m, dtype=np.int32)
+        ids, sc = dev.topn_scan(users, N)
+        ms, events, rescored, used_bf16 = dev.scan_stats()
+        print('full config 5: %.1f ms in the kernel, %.1f state-machine events and %.1f exact re-scores per user' % (ms, events / m, rescored / m))
+        assert used_bf16 and events > 0 and rescored >= events - m * N
+        assert ids.min() >= 0 and ids.max() < n
+        assert (np.diff(sc, axis=1) <= 0).all()
+        # no training item in any list: (user, item) keys of the lists against the sorted keys of the CSR
+        train_keys = np.repeat(np.arange(m, dtype=np.int64), np.diff(data['indptr'])) * n + data['indices']
+        list_keys = (np.arange(m, dtype=np.int64)[:, None] * n + ids).ravel()
+        pos = np.searchsorted(train_keys, list_keys)
+        pos[pos == len(train_keys)] = 0
+        assert not (train_keys[pos] == list_keys).any()
+        sample = np.linspace(0, m - 1, 32).astype(np.int32)
+        for u in sample:
+            s = dev.scores(int(u))
+            s[data['indices'][data['indptr'][u]:data['indptr'][u + 1]]] = -np.inf
+            assert ids[u, 0] == int(np.argmax(s)) and sc[u, 0] == s.max()
+            assert np.array_equal(sc[u], dev.scores(int(u))[ids[u]])
+        oid, osc, rc = orc.topn_scan(P, Q, sample, N, *mask_rows(data['indptr'], data['indices'], sample))
+        assert rc == 0 and np.array_equal(ids[sample], oid) and np.array_equal(sc[sample], osc)
+    finally:
+        dev.close()
