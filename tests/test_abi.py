@@ -28,6 +28,15 @@ def test_library_exports_header_symbols(built):
     assert lib.yue_version() >= 1
 
 
+def test_product_library_has_no_test_seam(built):
+    # the host-staged collective of tests/test_gpu_multi.py exists in libyue_hip_seam.so only
+    blob = open(built.LIB_PATH, 'rb').read()
+    assert b'yue_seam_init' not in blob
+    assert not hasattr(ctypes.CDLL(built.LIB_PATH), 'yue_seam_init')
+    seam = os.path.join(os.path.dirname(built.LIB_PATH), 'libyue_hip_seam.so')
+    assert os.path.exists(seam) and hasattr(ctypes.CDLL(seam), 'yue_seam_init')
+
+
 def test_code_object_targets_gfx950(built):
     blob = open(built.LIB_PATH, 'rb').read()
     assert b'gfx950' in blob

@@ -1,7 +1,9 @@
 """GPU: the communicator path of yue_bpr_epoch (user-aligned blocks, RCCL all-reduce of the block's
 user-factor differences in place, range apply) with a 1-rank communicator on the one GPU we have,
 against the executable spec that tests/test_dist_cpu.py runs on two CPU ranks; and the real thing --
-two processes, two GPUs, RCCL -- wherever the box has two devices (skipped otherwise)."""
+two processes, two GPUs, RCCL -- wherever the box has two devices (skipped otherwise); and, on ANY box, two ranks on
+one GPU with the collective behind the test seam of libyue_hip_seam.so (the block / group / two-stream logic of the
+communicator path with more than one rank; RCCL itself still runs with one rank only on a one-GPU box)."""
 import numpy as np
 import pytest
 
@@ -31,6 +33,67 @@ def test_communicator_epoch_matches_sharded_spec(orc):
     dev.close()
 
 
+def _two_shard_reference(orc, m, n, d, k, W, epochs):
+    """Single-process emulation of the two shards with oracle arithmetic (as tests/test_dist_cpu.py does)."""
+    from test_dist_cpu import epoch_spec_blocks
+    shards = [shard_problem(r, m, n, d, k) for r in range(2)]
+    P = shards[0][1].copy()
+    Qs = [sh[2].copy() for sh in shards]
+    etot = float(sum(sh[0]['ev_ptr'][-1] for sh in shards))
+    for epoch in range(epochs):
+        blocks = [[], []]
+        for r in range(2):
+            epoch_spec_blocks(orc, blocks[r], r, shards[r][0], P.copy(), Qs[r], 31, epoch, W, 0.05, 0.01, 0.01, etot)
+        for (u0, u1, b0), (_, _, b1) in zip(blocks[0], blocks[1]):
+            P[u0:u1] += b0 + b1
+    return P, Qs, etot
+
+
+def _spawn_two_ranks(tmp_path, script, args, local_ranks):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(local_ranks[r]), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'helpers', script), str(tmp_path)] + [str(x) for x in args],
+                                      cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-3000:]
+
+
+def test_two_rank_epoch_on_one_gpu_through_the_test_seam(tmp_path, orc):
+    """Two processes on device 0, item shards 0 and 1, the real yue_bpr_epoch on a 2-rank "communicator" whose collective is
+    the test seam (host-staged sum over the control plane).  Several groups of user blocks per epoch (m * k * 4 = 15 MB against
+    8 MB per group), so the second stream's reduce + apply really runs beside the next group's rounds.  Replicated user factors
+    must come out bit-identical on both ranks and within 1e-5 of the two-shard spec."""
+    import os
+    from yue_amd.dist import epoch_block_plan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, 'yue_amd', 'csrc', 'libyue_hip_seam.so')):
+        pytest.fail('yue_amd/csrc/libyue_hip_seam.so missing: run __graft_entry__.build() (make -C yue_amd/csrc test-seam)')
+    m, n, d, k, W, epochs = 30000, 4000, 12, 128, 16384, 2
+    _spawn_two_ranks(tmp_path, 'seam_rank_main.py', (m, n, d, k, W, epochs), (0, 0))
+    r0, r1 = np.load(tmp_path / 'seam_rank0.npz'), np.load(tmp_path / 'seam_rank1.npz')
+    assert np.array_equal(r0['P'], r1['P'])                       # replicated user factors stay bit-identical
+    assert r0['nll_total'] == r1['nll_total'] and abs(r0['nll_total'] - (r0['nll'] + r1['nll'])) <= 1e-9 * abs(r0['nll_total'])
+    P, Qs, etot = _two_shard_reference(orc, m, n, d, k, W, epochs)
+    assert rel_err(r0['P'], P) < 1e-5 and rel_err(r0['Q'], Qs[0]) < 1e-5 and rel_err(r1['Q'], Qs[1]) < 1e-5
+    # the library reduced exactly the groups the plan announces: every user row once per epoch
+    plan = epoch_block_plan(m, k, W, etot, 2)
+    assert len(plan['groups']) > 1
+    for r in (r0, r1):
+        assert int(r['collectives']) == len(plan['groups']) and int(r['nranks']) == 2
+        assert float(r['allreduce_bytes']) == 4.0 * m * k and int(r['elements']) == epochs * m * k
+
+
 def _device_count():
     import ctypes
     try:
@@ -44,39 +107,12 @@ def _device_count():
 def test_two_rank_product_epoch(tmp_path, orc):
     # two processes, one GPU each, the library's RCCL all-reduce between them (never run on the 1-GPU test boxes:
     # there it is skipped and the RCCL path stays verified for one rank only)
-    import os
-    import socket
-    import subprocess
-    import sys
     if _device_count() < 2:
         pytest.skip('needs two GPUs')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     m, n, d, k, W, epochs = 3000, 2000, 25, 128, 4096, 2
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'helpers', 'gpu_rank_main.py'), str(tmp_path)] + [str(x) for x in (m, n, d, k, W, epochs)],
-                                      cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for p in procs:
-        out, _ = p.communicate(timeout=600)
-        assert p.returncode == 0, out.decode()[-3000:]
+    _spawn_two_ranks(tmp_path, 'gpu_rank_main.py', (m, n, d, k, W, epochs), (0, 1))
     r0, r1 = np.load(tmp_path / 'gpu_rank0.npz'), np.load(tmp_path / 'gpu_rank1.npz')
     assert np.array_equal(r0['P'], r1['P'])                       # replicated user factors stay bit-identical
     assert r0['nll_total'] == r1['nll_total'] and abs(r0['nll_total'] - (r0['nll'] + r1['nll'])) <= 1e-9 * abs(r0['nll_total'])
-    # single-process emulation of the two shards with oracle arithmetic (as tests/test_dist_cpu.py does)
-    from test_dist_cpu import epoch_spec_blocks
-    shards = [shard_problem(r, m, n, d, k) for r in range(2)]
-    P = shards[0][1].copy()
-    Qs = [sh[2].copy() for sh in shards]
-    etot = float(sum(sh[0]['ev_ptr'][-1] for sh in shards))
-    for epoch in range(epochs):
-        blocks = [[], []]
-        for r in range(2):
-            epoch_spec_blocks(orc, blocks[r], r, shards[r][0], P.copy(), Qs[r], 31, epoch, W, 0.05, 0.01, 0.01, etot)
-        for (u0, u1, b0), (_, _, b1) in zip(blocks[0], blocks[1]):
-            P[u0:u1] += b0 + b1
+    P, Qs, _ = _two_shard_reference(orc, m, n, d, k, W, epochs)
     assert rel_err(r0['P'], P) < 1e-5 and rel_err(r0['Q'], Qs[0]) < 1e-5 and rel_err(r1['Q'], Qs[1]) < 1e-5

@@ -570,7 +570,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     if (c->opt_epoch_exact) {
         // exact sequential semantics over the epoch's triplets (the reference's loop, BPR.py:42-58, on the device sampler's
         // negatives): one dataflow launch, no rounds.  One GPU only: the order of the whole stream is the semantics.
-        if (c->comm && c->nranks > 1) return fail(YUE_ERR_ARG, "yue_bpr_epoch: option epoch_exact runs on one GPU (the sequential order spans all item shards)");
+        if (yue_host::on_communicator(c) && c->nranks > 1) return fail(YUE_ERR_ARG, "yue_bpr_epoch: option epoch_exact runs on one GPU (the sequential order spans all item shards)");
         if ((rc = yue_host::chain_epoch(c, lr, regU, regI))) return rc;
         if ((rc = sumsq_async(c))) return rc;
         return read_scalars(c, nll_out, sumsqP_out, sumsqQ_out);
@@ -583,7 +583,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     // the same blocks on every rank.
     std::vector<int64_t> bounds;
     double tot[2] = {(double)E, (double)c->n};            // job-wide events and item rows
-    if (c->comm) {
+    if (yue_host::on_communicator(c)) {
         if ((rc = yue_allreduce_f64(c, tot, 2))) return rc;
         if ((rc = zero_scalars(c))) return rc;            // the all-reduce used the scalar scratch
     }
@@ -600,7 +600,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
         const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
         const dim3 grid((unsigned)std::min<int64_t>(4096, (count + 255) / 256));
-        if (!c->comm) {
+        if (!yue_host::on_communicator(c)) {
             // one GPU: nothing to wait for -- apply between two rounds on the compute stream (a few microseconds per
             // group; on a second stream its workgroups would take residency slots from the round kernel, which
             // fills the chip exactly, and push single launches into a second wave generation)
@@ -618,7 +618,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     c->comm_collectives = 0; c->comm_bytes = 0.0; c->comm_wait_ms = 0.0;
     if ((rc = run_rounds(c, a, bounds, 0, after, meta_path_fits(c)))) { reset_round_state(c); return rc; }
     // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
-    if (c->comm) {       // how long the compute stream has to wait for the last group's all-reduce + apply
+    if (yue_host::on_communicator(c)) {       // how long the compute stream has to wait for the last group's all-reduce + apply
         HIPCHK(hipEventRecord(c->ev_t_rounds, c->stream));
         HIPCHK(hipEventRecord(c->ev_t_comm, c->comm_stream));
     }
@@ -627,7 +627,7 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
     if ((rc = read_scalars(c, nll_out, sumsqP_out, sumsqQ_out))) return rc;
-    if (c->comm) {
+    if (yue_host::on_communicator(c)) {
         float ms = 0.f;
         HIPCHK(hipEventSynchronize(c->ev_t_comm));
         HIPCHK(hipEventElapsedTime(&ms, c->ev_t_rounds, c->ev_t_comm));
@@ -652,7 +652,7 @@ int yue_default_round_events(yue_ctx *c, int64_t *out) {
     if (!c || !c->have_factors || !out) return fail(YUE_ERR_ARG, "yue_default_round_events: upload factors first (the value depends on k)");
     HIPCHK(hipSetDevice(c->device));
     double n_rows = (double)c->n;
-    if (c->comm) {                                         // collective on a communicator: every rank gets the same value
+    if (yue_host::on_communicator(c)) {                    // collective on a communicator: every rank gets the same value
         const int rc = yue_allreduce_f64(c, &n_rows, 1);
         if (rc) return rc;
         n_rows /= c->nranks;

@@ -139,6 +139,12 @@ struct yue_ctx {
     hipStream_t comm_stream = nullptr;   // (all-reduce +) user-row apply of yue_bpr_epoch run here, beside the next rounds
     hipEvent_t ev_rounds = nullptr, ev_comm = nullptr;
     hipEvent_t ev_t_rounds = nullptr, ev_t_comm = nullptr;   // timing pair of the last epoch on a communicator: end of its round launches / end of its last apply
+    // TEST SEAM (libyue_hip_seam.so only, make test-seam: the product library has no way to set these): the collective of
+    // reduce_user_block / yue_allreduce_f64 as a host-staged sum through a callback, so that the 2-rank block / group /
+    // stream logic of yue_bpr_epoch runs on a one-GPU box (tests/test_gpu_multi.py).  dtype 0 = float, 1 = double.
+    int (*seam_reduce)(void *host, int64_t count, int dtype, void *user) = nullptr;
+    void *seam_user = nullptr;
+    std::vector<float> seam_buf;
     // communicator statistics of the last yue_bpr_epoch (yue_get_comm_stats)
     int64_t comm_collectives = 0;
     double comm_bytes = 0.0, comm_wait_ms = 0.0;
@@ -147,6 +153,7 @@ struct yue_ctx {
 };
 
 namespace yue_host {
+inline bool on_communicator(const yue_ctx *c) { return c->comm != nullptr || c->seam_reduce != nullptr; }
 // bpr_host.hip: loss / scalar scratch shared by the training entry points
 int zero_scalars(yue_ctx *c);
 int read_scalars(yue_ctx *c, double *nll, double *sp, double *sq);
