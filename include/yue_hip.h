@@ -173,6 +173,8 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *   "round_bucket" 1: the bucketed pre-pass also for small catalogues (tests)
  *   "fold_blocks" workgroups of the fold launch (default 1536)
  *   "chain_waves" exact path: workgroups (of four waves) per CU of the dataflow launch, 1..8 (0 = default: 1)
+ *   "chain_split" exact path: 1 = a run is walked by a PAIR of waves (k_bpr_chain2: one keeps the memory side, the other the
+ *               dependency chain margin -> sigmoid -> user row; same results bit for bit; measured no faster: default 0)
  *   "chain_spin"  exact path: polls a wave spends on one wait before it gives up with an error (0 = default: 2^22)
  * Behaviour switches:
  *   "epoch_exact" 1 = yue_bpr_epoch applies the epoch's triplets (device sampler's negatives) with the reference's exact

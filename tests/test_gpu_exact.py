@@ -130,3 +130,23 @@ def test_a_wave_that_cannot_get_its_row_gives_up_instead_of_hanging(dev):
         dev.set_option('epoch_exact', 0)
     dev.set_factors(P0, Q0)
     assert np.isfinite(dev.bpr_epoch(5, 0, 512, 0.02, 0.01, 0.01)[0])
+
+
+@pytest.mark.parametrize('m,n,d,k', [(3000, 2000, 20, 128), (5000, 64, 12, 64), (700, 900, 70, 10), (400, 300, 25, 200)])
+def test_two_wave_variant_is_bit_equal(dev, m, n, d, k):
+    """Option chain_split: a run walked by a pair of waves (memory side / dependency chain, hand-over through LDS) must produce
+    exactly the factors and the loss of the one-wave kernel (70 events per user: runs longer than one segment of 64)."""
+    data, ev_u, P0, Q0 = _problem(m, n, d, k, 7)
+    res = []
+    for split in (0, 1):
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        dev.set_option('epoch_exact', 1)
+        dev.set_option('chain_split', split)
+        try:
+            nll = dev.bpr_epoch(9, 0, 0, 0.02, 0.01, 0.01)[0]
+        finally:
+            dev.set_option('epoch_exact', 0)
+            dev.set_option('chain_split', 0)
+        res.append((nll,) + dev.get_factors())
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

@@ -87,10 +87,17 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     // ring of 8 triplets per wave (4 for k > 128: register budget)
 #define YUE_CHAIN_RUN(KR_, PV_, G_)                                                                                                   \
     do {                                                                                                                                \
+        if (c->opt_chain_split) {                                                                                                       \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain2<KR_, PV_, G_>, 256, 0));                     \
+            per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 1));                                   \
+            grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 1) / 2)));                        \
+            hipLaunchKernelGGL((yue::k_bpr_chain2<KR_, PV_, G_>), grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p); \
+        } else {                                                                                                                        \
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain<KR_, PV_, G_>, 256, 0));                          \
         per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 1));                                       \
         grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 3) / 4)));                            \
         hipLaunchKernelGGL((yue::k_bpr_chain<KR_, PV_, G_>), grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p);  \
+        }                                                                                                                               \
     } while (0)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     if (ord_u) { if (kr == 1) YUE_CHAIN_RUN(1, true, 8); else if (kr == 2) YUE_CHAIN_RUN(2, true, 8); else YUE_CHAIN_RUN(4, true, 4); }
@@ -108,6 +115,10 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     {
         unsigned long long h[8];
         HIPCHK(hipMemcpy(h, c->ch_stats.p, sizeof h, hipMemcpyDeviceToHost));
+        if (c->opt_chain_split)
+            fprintf(stderr, "[chain2 stats] wave C: %.0f cycles of work and %.0f cycles of waiting for rows per packet (%llu packets); wave M: %.0f cycles waiting for a coefficient (%llu triplets)\n",
+                    h[1] ? (double)h[0] / h[1] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, h[1], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
+        else
         fprintf(stderr, "[chain stats] steps without a wait: %llu, %.0f cycles each; steps that waited: %llu (%.2f %%), %.0f cycles each; per run outside the steps: %.0f cycles (%llu runs)\n",
                 h[1], h[1] ? (double)h[0] / h[1] : 0.0, h[3], 100.0 * h[3] / (double)(h[1] + h[3] + 1e-9), h[3] ? (double)h[2] / h[3] : 0.0, h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
     }

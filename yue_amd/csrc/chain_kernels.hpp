@@ -411,4 +411,335 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
     if (lane == 0 && nl != 0.0) atomicAdd(a.nll_slots + (wave_slot & (kNllSlots - 1)), nl);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same dataflow with the work of a run split over TWO waves (a pair on two SIMDs of one CU).  A lone wave issues its
+// instructions one after the other, so the time of a step is the number of its instructions: ~200 in k_bpr_chain, of which
+// the next triplet of the run only needs the margin, the sigmoid and the new user row (~85).
+//   wave M ("memory"): everything of k_bpr_chain except the margin -- claim, headers, the ring of prefetched rows with its
+//       counted waits, version checks and polling, the item-row updates and their granule stores, the user row at the end.
+//       It PUBLISHES the two rows of the next triplet in LDS before it waits for the coefficient of the current one;
+//   wave C ("chain"): reads published rows from LDS, computes the two dots, the sigmoid and c = fp32(lr (1 - s)), hands c back
+//       through LDS, updates its copy of the user row, keeps the loss.  It never touches global memory.
+// Both waves keep the user row and update it with the same instructions, so only c crosses back.  Packets M -> C carry a
+// sequence number that grows over the whole launch (slot = number mod kPairRing): a stale slot never matches.  LDS serves a
+// wave's operations in order, so "rows, then tag" written by M and "tag, then rows" read by C need no fence.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kPairRing = 8;
+constexpr unsigned kPktEvent = 0u, kPktStart = 1u, kPktExit = 2u;
+
+template <int KR>
+struct PairBox {
+    float rows[kPairRing][2 * KR][64];     // event: qi[0..KR), qj[0..KR); start: the user row in [0..KR)
+    unsigned tag[kPairRing];               // (sequence number << 2) | packet type
+    unsigned cbits[kPairRing];             // the coefficient of the slot's triplet
+    unsigned cseq[kPairRing];              // sequence number it belongs to
+};
+
+// LDS words shared by the two waves of a pair: relaxed workgroup-scope atomics (plain ds_read / ds_write, never hoisted or
+// merged by the compiler, no waits on the vector-memory queue) between compiler barriers; the LDS keeps a wave's operations in order.
+__device__ __forceinline__ unsigned lds_get(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_put(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float lds_getf(const float *p) { return __builtin_bit_cast(float, lds_get(reinterpret_cast<const unsigned *>(p))); }
+__device__ __forceinline__ void lds_putf(float *p, float v) { lds_put(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v)); }
+
+template <int KR, bool PVER, int G>
+__global__ void __launch_bounds__(256) k_bpr_chain2(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
+                                                    const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
+    constexpr int GR = KR, GB = 8;
+    typedef Gran GT;
+    typedef typename GT::reg greg;
+    __shared__ PairBox<KR> boxes[2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    PairBox<KR> &box = boxes[wave >> 1];
+    if ((wave & 1) == 0 && lane < kPairRing) { box.tag[lane] = 0u; box.cseq[lane] = 0u; }
+    __syncthreads();
+
+    if ((wave & 1) == 0) {
+        // ---------------------------------------------------------------- wave C: margin, sigmoid, coefficient, user row, loss
+        float p[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) p[r] = 0.0f;
+        double nl = 0.0, sv = 1.0;
+        unsigned nsv = 0, seq = 1;
+        YUE_CS(unsigned long long cs_work = 0, cs_wait = 0, cs_n = 0;)
+        for (;;) {
+            const unsigned slot = seq & (kPairRing - 1);
+            unsigned tg;
+            YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter();)
+            while (((tg = lds_get(&box.tag[slot])) >> 2) != seq) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            YUE_CS(const unsigned long long cs_t1 = __builtin_readcyclecounter(); cs_wait += cs_t1 - cs_t0;)
+            const unsigned type = tg & 3u;
+            if (type == kPktExit) break;
+            float d[2 * KR];
+#pragma unroll
+            for (int r = 0; r < 2 * KR; ++r) d[r] = lds_getf(&box.rows[slot][r][lane]);
+            if (type == kPktStart) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) p[r] = d[r];
+                ++seq;
+                continue;
+            }
+            float ai = 0.0f, aj = 0.0f;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float mi = p[r] * d[r], mj = p[r] * d[KR + r]; ai = ai + mi; aj = aj + mj; }
+            const float x = wave_sum(ai) - wave_sum(aj);                 // BPR.py:50, fp32 margin
+            const double xd = (double)x;
+            double sg;
+            if (__builtin_fabs(xd) <= 700.0) sg = chain_rcp(1.0 + chain_exp(-xd));     // qmath.py:115-116
+            else sg = 1.0 / (1.0 + exp(-xd));
+            const float c = (float)(a.lr * (1.0 - sg));
+            if (lane == 0) { lds_put(&box.cbits[slot], __builtin_bit_cast(unsigned, c)); asm volatile("" ::: "memory"); lds_put(&box.cseq[slot], seq); }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {                               // BPR.py:51, :55 on the user row (as bpr_elem)
+                const float dd = d[r] - d[KR + r];
+                const float td = c * dd;
+                const float p1 = p[r] + td;
+                const float rpp = a.ru * p1;
+                p[r] = p1 - rpp;
+            }
+            sv = (unsigned)lane == nsv ? sg : sv;
+            if (++nsv == 64u) { nl += -log(sv); nsv = 0; }              // BPR.py:58, 64 logs at a time
+            ++seq;
+            YUE_CS(cs_work += __builtin_readcyclecounter() - cs_t1; ++cs_n;)
+        }
+        YUE_CS(if (lane == 0) { atomicAdd(a.stats + 0, cs_work); atomicAdd(a.stats + 1, cs_n); atomicAdd(a.stats + 2, cs_wait); atomicAdd(a.stats + 3, cs_n); })
+        if ((unsigned)lane < nsv) nl += -log(sv);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) nl += __shfl_xor(nl, off);
+        if (lane == 0 && nl != 0.0) atomicAdd(a.nll_slots + ((blockIdx.x * 2 + (wave >> 1)) & (kNllSlots - 1)), nl);
+        return;
+    }
+
+    // -------------------------------------------------------------------- wave M: memory side
+    const unsigned k = (unsigned)a.k;
+    const unsigned row_bytes = (unsigned)GR * 64u * GB;
+    unsigned vo[GR];
+#pragma unroll
+    for (int g = 0; g < GR; ++g) vo[g] = (64u * g + lane) * GB;
+    const unsigned v_oob = kOobOffset;
+    const uint64_t qbytes = (uint64_t)a.n * row_bytes;
+    const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
+    i32x4 rq;
+    { const uint64_t qa = (uint64_t)a.Qv; rq.x = (int)(uint32_t)qa; rq.y = (int)((uint32_t)(qa >> 32) & 0xffffu); rq.z = qrec; rq.w = kRsrcFlags; }
+    unsigned seq = 1;                                    // next packet number
+    bool dead = false;
+    YUE_CS(unsigned long long cs_mwait = 0, cs_mn = 0;)
+
+    auto all_mine = [&](uint32_t want, const greg (&g)[GR]) -> bool {
+        bool mine = true;
+#pragma unroll
+        for (int q = 0; q < GR; ++q) mine = mine && GT::is(g[q], want);
+        return __builtin_amdgcn_ballot_w64(!mine) == 0ull;
+    };
+    auto acquire_slow = [&](const i32x4 &rs, unsigned so, uint32_t want, greg (&g)[GR]) -> bool {
+        uint32_t polls = 0;
+        bool fresh = false;
+        for (;;) {
+            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(g[0])) : 0u;
+            fresh = true;
+            while ((int32_t)dist > 1) {
+                const uint32_t naps = dist < 16u ? dist : 16u;
+                for (uint32_t q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(20);
+                greg one[1];
+                const unsigned v1 = lane == 0 ? 0u : kOobOffset;
+                GT::load(one[0], v1, rs, so);
+                row_wait_all<1>(one);
+                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(one[0]));
+                if (++polls > a.spin_limit || (int32_t)dist < 0) break;
+                if ((polls & 63u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            }
+            if ((int32_t)dist < 0 || ++polls > a.spin_limit) { if (lane == 0) atomicOr(a.status, (int32_t)dist < 0 ? 2u : 1u); return false; }
+            if ((polls & 255u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+#pragma unroll
+            for (int q = 0; q < GR; ++q) GT::load(g[q], vo[q], rs, so);
+            row_wait_all<GR>(g);
+            if (all_mine(want, g)) return true;
+        }
+    };
+    // a packet to wave C: 2 KR values per lane (or KR for the user row), then the tag
+    auto publish = [&](unsigned type, const float (&v)[2 * KR], int count) {
+        const unsigned slot = seq & (kPairRing - 1);
+#pragma unroll
+        for (int r = 0; r < 2 * KR; ++r) if (r < count) lds_putf(&box.rows[slot][r][lane], v[r]);
+        asm volatile("" ::: "memory");
+        if (lane == 0) lds_put(&box.tag[slot], (seq << 2) | type);
+        ++seq;
+    };
+
+    while (!dead) {
+        unsigned long long run = 0;
+        if (lane == 0) run = atomicAdd(a.claim, 1ull);
+        run = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(run >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)run);
+        if ((int64_t)run >= a.R) break;
+        const int64_t e0 = a.run_ptr[run], e1 = a.run_ptr[run + 1];
+        if (e1 <= e0) continue;
+        const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
+        const unsigned len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
+
+        float p[GR];
+        uint32_t pver = 0u;
+        i32x4 rp;
+        if (PVER) {
+            const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * (row_bytes / 4u));
+            rp.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)pa); rp.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xffffu));
+            rp.z = (int)row_bytes; rp.w = kRsrcFlags;
+            asm volatile("s_nop 4" : "+s"(rp));                       // VALU-written SGPRs, vector memory in assembly: see k_bpr_chain
+            pver = a.ord_u[run];
+            greg g[GR];
+#pragma unroll
+            for (int q = 0; q < GR; ++q) GT::load(g[q], vo[q], rp, 0u);
+            row_wait_all<GR>(g);
+            if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) { dead = true; break; }
+#pragma unroll
+            for (int q = 0; q < GR; ++q) p[q] = GT::value(g[q]);
+        } else {
+            const float *prow = a.P + (uint64_t)u * k;
+#pragma unroll
+            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; p[q] = e < k ? prow[e] : 0.0f; }
+        }
+        {   // the user row to wave C
+            float v[2 * KR];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { v[r] = p[r]; v[KR + r] = 0.0f; }
+            publish(kPktStart, v, KR);
+        }
+
+        for (unsigned seg = 0; seg < len && !dead; seg += 64u) {
+            int hAi, hAj;
+            uint32_t hAwi, hAwj;
+            {
+                const bool ex = seg + (unsigned)lane < len;
+                const int64_t e = e0 + seg + (ex ? lane : 0);
+                hAi = evi[e]; hAj = evj[e]; hAwi = ordi[e]; hAwj = ordj[e];
+                if (!ex) { hAi = 0; hAj = -1; }
+            }
+            greg gi[G][GR], gj[G][GR];
+            auto fill = [&](int s, int i_, int j_) {
+                const bool live = j_ >= 0;
+                const unsigned oi = live ? (unsigned)i_ * row_bytes : 0u, oj = live ? (unsigned)j_ * row_bytes : 0u;
+#pragma unroll
+                for (int q = 0; q < GR; ++q) {
+                    const unsigned v = live ? vo[q] : v_oob;
+                    GT::load(gj[s][q], v, rq, oj); GT::load(gi[s][q], v, rq, oi);
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < GR; ++q) asm volatile("" : "+v"(p[q]));
+            asm volatile("" : "+v"(hAi), "+v"(hAj), "+v"(hAwi), "+v"(hAwj));
+#pragma unroll
+            for (int s = 0; s < G; ++s) fill(s, __builtin_amdgcn_readlane(hAi, s), __builtin_amdgcn_readlane(hAj, s));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+            const unsigned seg_len = len - seg < 64u ? len - seg : 64u;
+            // Counted waits as in k_bpr_chain: every step issues 2 GR stores and 2 GR loads; a slot's loads have at least
+            // (G - 2) whole steps behind them when the step BEFORE its own looks ahead at it.
+            // Step t: [rows of triplet t + 1: wait, check, publish (postponed if a row still waits for MY store of triplet t)]
+            // [coefficient of t from wave C] [update and store t] [postponed publish] [refill slot t with triplet t + G].
+            // Published-but-unanswered triplets: at most two, the ring of kPairRing slots never wraps onto them.
+            bool have = false;                                       // rows of the current triplet are published
+            unsigned cur_seq = 0;
+            // try to publish the rows of slot s (already waited for); false: a row does not carry its ordinal yet
+            auto try_publish = [&](int s, uint32_t wi, uint32_t wj) -> bool {
+                if (!all_mine(wj, gj[s]) || !all_mine(wi, gi[s])) return false;
+                float v[2 * KR];
+#pragma unroll
+                for (int q = 0; q < GR; ++q) { v[q] = GT::value(gi[s][q]); v[KR + q] = GT::value(gj[s][q]); }
+                publish(kPktEvent, v, 2 * KR);
+                return true;
+            };
+            for (unsigned ol = 0; ol < seg_len && !dead; ol += G) {
+                const bool more = ol + G < 64u;
+#pragma unroll
+                for (int s = 0; s < G; ++s) {
+                    const int ti = __builtin_amdgcn_readlane(hAi, ol + s), tj = __builtin_amdgcn_readlane(hAj, ol + s);
+                    const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, ol + s), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, ol + s);
+                    const unsigned oi = (unsigned)(ti < 0 ? 0 : ti) * row_bytes, oj = (unsigned)(tj < 0 ? 0 : tj) * row_bytes;
+                    const bool live = tj >= 0 && !dead;
+                    // the NEXT live triplet's slot and header (inside this group: slot s + 1; the first slot of the next group
+                    // is handled at that group's first step, after its own wait)
+                    if (live && !have) {                             // first triplet of a group / after a gap: publish it now
+                        ring_wait<GR, (G - 2) * 4 * GR>(gi[s], gj[s]);
+                        bool ok = try_publish(s, wi, wj);
+                        if (!ok) {
+                            ok = (all_mine(wj, gj[s]) || acquire_slow(rq, oj, wj, gj[s])) && (all_mine(wi, gi[s]) || acquire_slow(rq, oi, wi, gi[s]));
+                            if (ok) ok = try_publish(s, wi, wj);
+                        }
+                        if (!ok) dead = true;
+                        cur_seq = seq - 1u;
+                        have = ok;
+                    }
+                    bool done = false;
+                    if (live && !dead) {
+                        // look ahead: rows of the next triplet of this group
+                        bool next_pub = false, next_live = false;
+                        int nti = 0, ntj = -1; uint32_t nwi = 0u, nwj = 0u;
+                        if (s + 1 < G) {
+                            nti = __builtin_amdgcn_readlane(hAi, (ol + s + 1) & 63u); ntj = (ol + s + 1 < 64u) ? __builtin_amdgcn_readlane(hAj, (ol + s + 1) & 63u) : -1;
+                            nwi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, (ol + s + 1) & 63u); nwj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, (ol + s + 1) & 63u);
+                            next_live = ntj >= 0;
+                            if (next_live) {
+                                ring_wait<GR, (G - 2) * 4 * GR>(gi[(s + 1) % G], gj[(s + 1) % G]);
+                                next_pub = try_publish((s + 1) % G, nwi, nwj);
+                            }
+                        }
+                        // the coefficient of this triplet
+                        const unsigned cslot = cur_seq & (kPairRing - 1);
+                        YUE_CS(const unsigned long long cs_m0 = __builtin_readcyclecounter();)
+                        while (lds_get(&box.cseq[cslot]) != cur_seq) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                        YUE_CS(cs_mwait += __builtin_readcyclecounter() - cs_m0; ++cs_mn;)
+                        const float c = __builtin_bit_cast(float, lds_get(&box.cbits[cslot]));
+#pragma unroll
+                        for (int q = 0; q < GR; ++q) {
+                            const float qi = GT::value(gi[s][q]), qj = GT::value(gj[s][q]);
+                            const Elem o = bpr_elem(p[q], qi, qj, c, a.ru, a.ri);
+                            p[q] = o.p2;
+                            GT::store(GT::make(o.qi2, wi + 1u), vo[q], rq, oi);
+                            GT::store(GT::make(o.qj2, wj + 1u), vo[q], rq, oj);
+                        }
+                        done = true;
+                        have = false;
+                        if (next_live) {
+                            if (!next_pub) {                         // its row waited for the stores just issued (or for another wave)
+                                const unsigned noi = (unsigned)nti * row_bytes, noj = (unsigned)ntj * row_bytes;
+                                bool ok = (all_mine(nwj, gj[(s + 1) % G]) || acquire_slow(rq, noj, nwj, gj[(s + 1) % G])) &&
+                                          (all_mine(nwi, gi[(s + 1) % G]) || acquire_slow(rq, noi, nwi, gi[(s + 1) % G]));
+                                if (ok) ok = try_publish((s + 1) % G, nwi, nwj);
+                                if (!ok) dead = true;
+                            }
+                            cur_seq = seq - 1u;
+                            have = !dead;
+                        }
+                    }
+                    if (!done) {
+                        greg z = GT::make(0.0f, 0u);
+#pragma unroll
+                        for (int q = 0; q < GR; ++q) { GT::store(z, v_oob, rq, 0u); GT::store(z, v_oob, rq, 0u); }
+                    }
+                    fill(s, more ? __builtin_amdgcn_readlane(hAi, (ol + G + s) & 63u) : 0, more ? __builtin_amdgcn_readlane(hAj, (ol + G + s) & 63u) : -1);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (dead) break;
+        if (PVER) {
+#pragma unroll
+            for (int q = 0; q < GR; ++q) GT::store(GT::make(p[q], pver + 1u), vo[q], rp, 0u);
+        } else {
+            float *prow = a.P + (uint64_t)u * k;
+#pragma unroll
+            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; if (e < k) prow[e] = p[q]; }
+        }
+    }
+    YUE_CS(if (lane == 0) { atomicAdd(a.stats + 4, cs_mwait); atomicAdd(a.stats + 5, cs_mn); })
+    {   // wave C leaves
+        float v[2 * KR];
+#pragma unroll
+        for (int r = 0; r < 2 * KR; ++r) v[r] = 0.0f;
+        publish(kPktExit, v, 0);
+    }
+}
+
 }  // namespace yue

@@ -130,6 +130,7 @@ struct yue_ctx {
     bool d_ev_ptr_valid = false;
     int opt_epoch_exact = 0;             // 1: yue_bpr_epoch applies the epoch's triplets with exact sequential semantics (k_bpr_chain)
     int opt_replay_levels = 0;           // 1: yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path)
+    int opt_chain_split = 0;             // 1: a run is walked by a pair of waves (k_bpr_chain2: memory side / dependency chain)
     int opt_chain_waves = 0;             // workgroups per CU of the persistent launch (0: what fits, at most 8)
     int64_t opt_chain_spin = 0;          // polls per wait before a wave gives up (0: 2^22)
     int64_t chain_runs = 0, chain_waves = 0, replay_levels = 0;
