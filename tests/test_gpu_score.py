@@ -244,3 +244,32 @@ def test_config5_at_its_stated_size(orc):
         assert rc == 0 and np.array_equal(ids[sample], oid) and np.array_equal(sc[sample], osc)
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize('m,n,k,N,per_user,signed', [(300, 40000, 128, 20, 60, True), (70, 33000, 64, 5, 2000, False), (130, 20000, 16, 64, 30, True),
+                                                   (40, 50001, 32, 10, 0, False), (257, 17000, 128, 1, 100, True)])
+def test_two_phase_scan_equals_the_fused_kernel_and_the_oracle(dev, orc, m, n, k, N, per_user, signed):
+    """Catalogues of 16,384 items and more take the chunked path (k_topn_scan_bf16p for the first 512 items, then
+    k_scan_filter + k_scan_select per chunk of doubling size): lists and scores must equal the oracle's and the fused
+    kernel's, with the overwrite-scan and as a true top-N, with ties, heavy masks (more than fit in LDS) and odd sizes."""
+    P, Q, indptr, indices = _rand_problem(m, n, k, per_user, seed=1000 + k + N, signed=signed)
+    Q[5000:5003] = Q[123]                                      # equal rows: ties between far-apart items
+    users = np.arange(m, dtype=np.int32)[::-1].copy()
+    mp, mi = mask_rows(indptr, indices, users)
+    dev.set_factors(P, Q)
+    for true_topn in (0, 1):
+        dev.set_option('topn_true', true_topn)
+        try:
+            ids, sc = dev.topn_scan(users, N, mp, mi)
+            assert dev.get_option('scan_last_chunks') >= 2
+            ms, events, rescored, used_bf16 = dev.scan_stats()
+            dev.set_option('scan_two_phase', 0)
+            ids_f, sc_f = dev.topn_scan(users, N, mp, mi)
+            assert dev.get_option('scan_last_chunks') == 0
+            _, events_f, _, _ = dev.scan_stats()
+        finally:
+            dev.set_option('scan_two_phase', 1)
+            dev.set_option('topn_true', 0)
+        assert np.array_equal(ids, ids_f) and np.array_equal(sc, sc_f) and events == events_f
+        oid, osc, rc = (orc.topn_true if true_topn else orc.topn_scan)(P, Q, users, N, mp, mi)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc)

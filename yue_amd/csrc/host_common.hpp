@@ -92,6 +92,11 @@ struct yue_ctx {
     double scan_ms = 0.0;
     int64_t scan_events = 0, scan_rescored = 0, scan_tiles_done = 0, scan_tiles_total = 0;
     DevBuf<unsigned long long> s_work;
+    DevBuf<unsigned short> s_qb;         // two-phase scoring: bf16 copy of the item factors
+    DevBuf<uint32_t> s_masks;            // ... and the survivor words of a chunk
+    int opt_scan_two_phase = 1;          // 0: always the fused kernels (k_topn_scan*)
+    int opt_scan_growth = 0;             // two-phase path: a chunk ends at this many times the items scanned so far (0: 2 or 8 by the first items' update rate)
+    int scan_chunks = 0;                 // chunks the last scan ran through the filter / select pair
     int scan_used_bf16 = 0;
     // options (yue_set_option)
     int opt_scan_f32 = 0;                // 1: always the exact-f32-MFMA scoring kernel

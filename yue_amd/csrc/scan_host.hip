@@ -1,7 +1,7 @@
 // libyue_hip.so -- predict and evalRanking's selection (include/yue_hip.h).
 #include "host_common.hpp"
 
-#include "score_kernels.hpp"
+#include "score2_kernels.hpp"
 
 using yue_host::fail;
 
@@ -31,7 +31,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     if (nu == 0) return YUE_OK;
     HIPCHK(hipSetDevice(c->device));
     for (int64_t t = 0; t < nu; ++t) if (users[t] < 0 || users[t] >= c->m) return fail(YUE_ERR_ARG, "yue_topn_scan: user id out of range");
-    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4)); HIPCHK(c->s_work.resize(4));
+    HIPCHK(c->s_users.resize(nu)); HIPCHK(c->s_ids.resize(nu * N)); HIPCHK(c->s_scores.resize(nu * N)); HIPCHK(c->s_flags.resize(4)); HIPCHK(c->s_work.resize(4 * yue::kWorkSlots));
     HIPCHK(hipMemcpyAsync(c->s_users.p, users, nu * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     yue::ScanArgs sa{};
     sa.P = c->P.p; sa.Q = c->Q.p; sa.n = c->n; sa.k = c->k; sa.users = c->s_users.p; sa.nu = nu; sa.N = N;
@@ -53,7 +53,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
         sa.mask_ptr = c->indptr.p; sa.mask_idx = c->indices.p; sa.mask_by_user = 1;
     }
     HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->s_work.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->s_work.p, 0, 4 * yue::kWorkSlots * sizeof(unsigned long long), c->stream));
     sa.work = c->s_work.p;
     const int64_t ntile = (c->n + 31) / 32;
     HIPCHK(c->s_norms.resize(2 * ntile));
@@ -63,7 +63,83 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     sa.tile_norm_sufmax = c->s_norms.p + ntile;
     const hipEvent_t t0 = c->ev_scan0, t1 = c->ev_scan1;
     HIPCHK(hipEventRecord(t0, c->stream));
-    int rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32, c->opt_scan_batch);
+    int rc = 0;
+    c->scan_chunks = 0;
+    // Long catalogues: the first chunk through the fused kernel (it seeds the lists), the rest in chunks of doubling size
+    // through k_scan_filter / k_scan_select (score2_kernels.hpp).  Same lists and scores by construction.
+    constexpr int64_t kChunk0 = 512;       // (the fused kernel is slow where the thresholds still move fast)
+    const bool two_phase = c->opt_scan_two_phase && !c->opt_scan_f32 && (c->k == 16 || c->k == 32 || c->k == 64 || c->k == 128) && N <= 64 &&
+                           c->n >= 16384 && yue::scan_bf16p_lds_bytes(c->k, N, 2, 8) <= 160u * 1024u;
+    bool done = false;
+    if (two_phase) {
+        yue::ScanArgs s0 = sa;
+        s0.n = kChunk0;
+        rc = yue::launch_scan(s0, c->stream, 0, 0);
+        int32_t few = 0;
+        std::vector<unsigned long long> w0(4 * yue::kWorkSlots, 0ull);
+        HIPCHK(hipMemcpyAsync(&few, c->s_flags.p, sizeof few, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(w0.data(), c->s_work.p, w0.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        unsigned long long ev0 = 0;
+        for (int q = 0; q < yue::kWorkSlots; ++q) ev0 += w0[(size_t)4 * q + 1];
+        // thresholds that still move fast (many list updates among the first items: e.g. untrained factors) want short chunks
+        const int growth = c->opt_scan_growth > 0 ? c->opt_scan_growth : ((double)ev0 / (double)nu > 4.0 * N ? 2 : 8);
+        if (few) {      // some user has fewer than N candidates among the first items: let the fused kernel walk everything
+            HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
+            HIPCHK(hipMemsetAsync(c->s_work.p, 0, 4 * yue::kWorkSlots * sizeof(unsigned long long), c->stream));
+        } else {
+            const int k = c->k;
+            const int64_t npad = (c->n + 63) / 64 * 64;
+            HIPCHK(c->s_qb.resize((size_t)npad * k));
+            hipLaunchKernelGGL(yue::k_q_to_bf16, dim3(2048), dim3(256), 0, c->stream, c->Q.p, reinterpret_cast<__bf16 *>(c->s_qb.p), c->n * (int64_t)k, npad * (int64_t)k);
+            int cus = 0;
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            // chunk boundaries and the widest chunk
+            std::vector<int64_t> cb{kChunk0};
+            while (cb.back() < c->n) cb.push_back(std::min<int64_t>(c->n, cb.back() * growth));
+            int64_t stride = 2;
+            for (size_t q = 0; q + 1 < cb.size(); ++q) stride = std::max<int64_t>(stride, ((cb[q + 1] - cb[q] + 127) / 128) * 4);
+            // users in slabs, so that the survivor words of a chunk stay below 12 GB
+            const int64_t slab = std::max<int64_t>(256, std::min<int64_t>(nu, ((12ll << 30) / (stride * 4)) / 256 * 256));
+            const int64_t sstride = (stride + 31) / 32 + 1;
+            HIPCHK(c->s_masks.resize((size_t)(std::min(slab, nu) * (stride + sstride))));
+            uint32_t *summary = c->s_masks.p + std::min(slab, nu) * stride;
+            yue::FilterArgs fa{};
+            fa.P = c->P.p; fa.Qb = reinterpret_cast<const __bf16 *>(c->s_qb.p); fa.N = N; fa.tile_norm_max = c->s_norms.p; fa.masks = c->s_masks.p;
+            fa.mask_stride = stride; fa.work = c->s_work.p; fa.n = c->n; fa.summary = summary; fa.sum_stride = sstride;
+            yue::SelectArgs xa{};
+            xa.P = c->P.p; xa.Q = c->Q.p; xa.n = c->n; xa.k = k; xa.N = N; xa.mask_ptr = sa.mask_ptr; xa.mask_idx = sa.mask_idx; xa.mask_by_user = sa.mask_by_user;
+            xa.masks = c->s_masks.p; xa.mask_stride = stride; xa.summary = summary; xa.sum_stride = sstride; xa.work = c->s_work.p; xa.true_topn = c->opt_topn_true;
+            constexpr int kSelWaves = 2;
+            const size_t sel_lds = yue::select_lds_bytes(kSelWaves);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&yue::k_scan_select<kSelWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+            for (int64_t u0 = 0; u0 < nu; u0 += slab) {
+                const int64_t un = std::min(slab, nu - u0);
+                fa.users = c->s_users.p + u0; fa.nu = un; fa.thr_rows = c->s_scores.p + u0 * N;
+                xa.users = c->s_users.p + u0; xa.nu = un; xa.ids = c->s_ids.p + u0 * N; xa.scores = c->s_scores.p + u0 * N;
+                // (an explicit mask is indexed by position in users[]: shift its row pointer with the slab)
+                if (!sa.mask_by_user) xa.mask_ptr = sa.mask_ptr + u0;
+                for (size_t q = 0; q + 1 < cb.size(); ++q) {
+                    fa.item0 = xa.item0 = cb[q]; fa.item1 = xa.item1 = cb[q + 1];
+                    constexpr int kUB = 1, kFW = 8;                // blocks of 32 users per wave of the filter, waves per workgroup (2 blocks per wave, 4 waves: measured 7 % slower)
+                    const int64_t ublocks = (un + 32 * kFW * kUB - 1) / (32 * kFW * kUB), iters = (cb[q + 1] - cb[q] + 63) / 64;
+                    const int64_t splits = std::max<int64_t>(1, std::min<int64_t>(iters, (2 * cus + ublocks - 1) / ublocks));
+                    fa.iters_per_block = ((iters + splits - 1) / splits + 15) / 16 * 16;      // a summary word (16 stages) belongs to one workgroup
+                    const dim3 fgrid((unsigned)ublocks, (unsigned)((iters + fa.iters_per_block - 1) / fa.iters_per_block));
+                    const size_t flds = 2u * 64u * (size_t)(k + yue::kScanBfPad) * 2u;
+#define YUE_FILTER(K16_) hipLaunchKernelGGL((yue::k_scan_filter<K16_, kFW, kUB>), fgrid, dim3(64 * kFW), flds, c->stream, fa)
+                    if (k == 16) YUE_FILTER(1); else if (k == 32) YUE_FILTER(2); else if (k == 64) YUE_FILTER(4); else YUE_FILTER(8);
+#undef YUE_FILTER
+                    hipLaunchKernelGGL((yue::k_scan_select<kSelWaves>), dim3((unsigned)((un + kSelWaves - 1) / kSelWaves)), dim3(64 * kSelWaves), sel_lds, c->stream, xa);
+                    if (u0 == 0) c->scan_chunks++;
+                }
+            }
+            HIPCHK(hipGetLastError());
+            done = true;
+            rc = 1;
+        }
+    }
+    if (!done) rc = yue::launch_scan(sa, c->stream, c->opt_scan_f32, c->opt_scan_batch);
     HIPCHK(hipEventRecord(t1, c->stream));
     if (rc < 0) return fail(YUE_ERR_ARG, "yue_topn_scan: unsupported (k, N) combination (k <= 256; for k > 128 the list length N is limited to 66)");
     c->scan_used_bf16 = rc;
@@ -72,12 +148,14 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipMemcpyAsync(out_ids, c->s_ids.p, nu * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out_scores, c->s_scores.p, nu * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(flags, c->s_flags.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
-    unsigned long long work[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(work, c->s_work.p, sizeof work, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> wslots(4 * yue::kWorkSlots, 0ull);
+    HIPCHK(hipMemcpyAsync(wslots.data(), c->s_work.p, wslots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, t0, t1));
     c->scan_ms = ms;
+    unsigned long long work[4] = {0, 0, 0, 0};
+    for (int q = 0; q < yue::kWorkSlots; ++q) for (int z = 0; z < 4; ++z) work[z] += wslots[(size_t)4 * q + z];
     c->scan_events = (int64_t)work[1];
     c->scan_rescored = (int64_t)work[2];
     c->scan_tiles_done = (int64_t)work[0];

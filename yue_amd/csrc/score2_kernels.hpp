@@ -1,0 +1,393 @@
+// Two-phase scoring for long item catalogues (k in {16, 32, 64, 128}, N <= 64): the same lists and scores as k_topn_scan*,
+// with the MFMA work and the sequential selection in separate launches.
+//
+// evalRanking's selection (base/IterativeRecommender.py:121-144) only ever acts on a candidate whose score exceeds the
+// user's current threshold a[N-1], and that threshold never falls.  So for a CHUNK of items scanned with the thresholds
+// the users had when the chunk started, a candidate whose exact score cannot exceed that older threshold can be dropped
+// without changing anything; everything else is looked at exactly, in ascending item order, as the reference does.
+//   k_scan_filter   (per chunk) bf16 MFMA scores of all users against the chunk's items; a pair survives if
+//                   bf16 score + 1.01 * 2^-7 ||P_u|| max||Q_tile|| > threshold_u (the error bound of score_kernels.hpp);
+//                   one 32-bit word per (user, tile of 32 items) -- nothing else: no state, no exact arithmetic, no
+//                   survivor handling in the matrix loop;
+//   k_scan_select   (per chunk) one wave per user: walks the user's words, gathers the surviving item rows 64 at a time
+//                   (coalesced row loads through a small LDS staging area, one survivor per lane), computes the exact
+//                   k-ascending fp32 fma chain per lane -- every lane busy -- and feeds the exact scores in ascending item
+//                   order through the reference's state machine, whose N slots live one per lane (an insert position is a
+//                   ballot + popcount, an overwrite one predicated move);
+// chunks grow geometrically (512, 512, 1024, ...), so a threshold is never staler than a factor two in items seen.
+// The first chunk runs through k_topn_scan_bf16p, which also seeds the lists (base/IterativeRecommender.py:107-116).
+#pragma once
+#include "score_kernels.hpp"
+
+namespace yue {
+
+struct FilterArgs {
+    const float *P;
+    const __bf16 *Qb;            // item factors rounded to bf16, rows padded with zero rows to a multiple of 64
+    const int32_t *users;
+    int64_t nu, n;               // users of this launch, items of the catalogue
+    int N;
+    const float *thr_rows;       // [nu][N] the lists' scores so far: threshold of user t = thr_rows[t * N + N - 1]
+    const float *tile_norm_max;  // max ||Q_i|| per tile of 32 items (global tile index)
+    int64_t item0, item1;        // the chunk; item0 is a multiple of 64
+    int64_t iters_per_block;     // stages of 64 items one workgroup takes (blockIdx.y-th share of the chunk)
+    uint32_t *masks;             // [nu][mask_stride]: word w of a user = tile item0 / 32 + w; only words with survivors are written
+    int64_t mask_stride;
+    uint32_t *summary;           // [nu][sum_stride]: bit b of word s = mask word 32 s + b was written (every word of the chunk's
+    int64_t sum_stride;          // range is written: no clearing between chunks)
+    unsigned long long *work;    // slots as ScanArgs.work: [0] += tiles scored
+};
+
+__global__ void __launch_bounds__(256) k_q_to_bf16(const float *Q, __bf16 *Qb, int64_t count, int64_t padded) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += stride) Qb[t] = t < count ? (__bf16)Q[t] : (__bf16)0.0f;
+}
+
+// A wave takes UB blocks of 32 users: one item-tile fragment read from LDS feeds UB MFMAs (at UB = 1 the LDS reads of the
+// fragments take as long as the MFMAs they feed: 16 x 1 KB per wave and 64 items against 16 x 32 cycles of the matrix pipe).
+template <int K16, int WAVES, int UB>
+__global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int K = 16 * K16, LDB = K + kScanBfPad, NT = 64 * WAVES, ROWS = 64;
+    __bf16 *btile = reinterpret_cast<__bf16 *>(lds_raw);                 // [2][64][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int64_t upos[UB];
+    bool uvalid[UB];
+    bf16x8 af[UB][K16];
+    float mu[UB], pn[UB], thr[UB];
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {
+        upos[b] = ((int64_t)blockIdx.x * WAVES + w) * (32 * UB) + 32 * b + r;
+        uvalid[b] = upos[b] < a.nu;
+        const int32_t uid = a.users[uvalid[b] ? upos[b] : 0];
+        const float *prow = a.P + (int64_t)uid * K;
+#pragma unroll
+        for (int s = 0; s < K16; ++s)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) af[b][s][jj] = (__bf16)prow[16 * s + 8 * h + jj];
+        float ss = 0.0f;
+        for (int e = h * (K / 2); e < (h + 1) * (K / 2); ++e) ss = __builtin_fmaf(prow[e], prow[e], ss);
+        ss = lo_bcast(ss) + hi_bcast(ss);
+        mu[b] = __builtin_sqrtf(ss) * (1.01f / 128.0f);        // the margin factors of k_topn_scan_bf16p
+        pn[b] = mu[b] * (128.0f * 1.0001f / 1.01f);
+        thr[b] = uvalid[b] ? a.thr_rows[upos[b] * a.N + a.N - 1] : INFINITY;
+    }
+
+    // one stage = 64 consecutive rows of Qb = ROWS * K * 2 bytes, contiguous; 16-byte pieces
+    constexpr int PIECES = ROWS * K * 2 / 16, PF = (PIECES + NT - 1) / NT;
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s pre[PF];
+    int ldo[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { const int pc = tid + NT * q; const int row = pc / (K / 8); ldo[q] = row * LDB + (pc - row * (K / 8)) * 8; }
+    auto fetch = [&](int64_t it0) {
+        const u32x4s *src = reinterpret_cast<const u32x4s *>(a.Qb + it0 * K);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) if (PIECES % NT == 0 || tid + NT * q < PIECES) pre[q] = src[tid + NT * q];
+    };
+    auto commit = [&](int stage) {
+        __bf16 *dst = btile + stage * ROWS * LDB;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) if (PIECES % NT == 0 || tid + NT * q < PIECES) *reinterpret_cast<u32x4s *>(dst + ldo[q]) = pre[q];
+    };
+
+    const int64_t niter_all = (a.item1 - a.item0 + ROWS - 1) / ROWS;
+    const int64_t it_begin = (int64_t)blockIdx.y * a.iters_per_block;
+    const int64_t niter = it_begin + a.iters_per_block < niter_all ? it_begin + a.iters_per_block : niter_all;
+    unsigned tiles_done = 0;
+    uint32_t summ[UB];                                       // lanes (r, 0): which of the running 32 mask words have survivors
+#pragma unroll
+    for (int b = 0; b < UB; ++b) summ[b] = 0u;
+    if (it_begin >= niter) return;
+    fetch(a.item0 + it_begin * ROWS);
+    commit((int)(it_begin & 1));
+    __syncthreads();
+    for (int64_t it = it_begin; it < niter; ++it) {
+        const int stage = (int)(it & 1);
+        const int64_t it0 = a.item0 + it * ROWS;
+        const __bf16 *tbb = btile + stage * ROWS * LDB;
+        if (it + 1 < niter) fetch(it0 + ROWS);
+        const int64_t tl = it0 / kScanTile;
+        const float nu0 = a.tile_norm_max[tl], nu1 = (it0 + kScanTile < a.n) ? a.tile_norm_max[tl + 1] : 0.0f;
+        bool settled = true;                                 // Cauchy-Schwarz: no exact score of these tiles reaches the threshold
+#pragma unroll
+        for (int b = 0; b < UB; ++b) settled = settled && (!uvalid[b] || pn[b] * fmaxf(nu0, nu1) <= thr[b]);
+        if (__ballot(!settled) != 0ull) {
+            tiles_done += 2 * UB;
+            uint32_t pm[UB][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x16 acc[UB];
+#pragma unroll
+                for (int b = 0; b < UB; ++b)
+#pragma unroll
+                    for (int z = 0; z < 16; ++z) acc[b][z] = 0.0f;
+                const __bf16 *irow = tbb + (q * kScanTile + r) * LDB + 8 * h;
+#pragma unroll
+                for (int s = 0; s < K16; ++s) {
+                    const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s);
+#pragma unroll
+                    for (int b = 0; b < UB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[b][s], acc[b], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < UB; ++b) {
+                    const float bar = thr[b] - mu[b] * (q ? nu1 : nu0);
+                    // most tiles hold no survivor for any user of the wave: one max over the lane's 16 scores decides that
+                    float mx = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]);
+#pragma unroll
+                    for (int z = 3; z < 15; z += 2) mx = fmaxf(fmaxf(mx, acc[b][z]), acc[b][z + 1]);
+                    mx = fmaxf(mx, acc[b][15]);
+                    pm[b][q] = 0u;
+                    if (__ballot(bar < mx) != 0ull) {
+                        uint32_t bits = 0u;
+#pragma unroll
+                        for (int z = 15; z >= 0; --z) bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(uint32_t, bar - acc[b][z]), 31);
+                        const uint32_t pmask = (bits & 0xFu) | ((bits & 0xF0u) << 4) | ((bits & 0xF00u) << 8) | ((bits & 0xF000u) << 12);
+                        pm[b][q] = pmask << (4 * h);
+                    }
+                }
+            }
+            const int64_t left = a.n - it0;                      // items of the catalogue from this stage on
+#pragma unroll
+            for (int b = 0; b < UB; ++b) {
+                if (__ballot((pm[b][0] | pm[b][1]) != 0u) == 0ull) continue;
+                uint32_t l0, h0, l1, h1;
+                half_bcast(pm[b][0], l0, h0); half_bcast(pm[b][1], l1, h1);
+                uint32_t p0 = l0 | h0, p1 = l1 | h1;
+                if (left < 64) { if (left <= 32) { p1 = 0u; if (left < 32) p0 &= (1u << (uint32_t)left) - 1u; } else p1 &= (1u << (uint32_t)(left - 32)) - 1u; }
+                if (h == 0 && uvalid[b] && (p0 | p1) != 0u) {
+                    uint32_t *dst = a.masks + upos[b] * a.mask_stride + (it0 - a.item0) / kScanTile;
+                    dst[0] = p0; dst[1] = p1;
+                    summ[b] |= ((p0 != 0u ? 1u : 0u) | (p1 != 0u ? 2u : 0u)) << (2 * (unsigned)(it & 15));
+                }
+            }
+        }
+        if ((it & 15) == 15 || it + 1 == niter) {                // 16 stages = 32 mask words = one summary word (a block's share starts at a multiple of 16)
+#pragma unroll
+            for (int b = 0; b < UB; ++b) {
+                if (h == 0 && uvalid[b]) a.summary[upos[b] * a.sum_stride + (it >> 4)] = summ[b];
+                summ[b] = 0u;
+            }
+        }
+        if (it + 1 < niter) commit(stage ^ 1);
+        __syncthreads();
+    }
+    if (lane == 0) atomicAdd(work_slot(a.work, (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + w), (unsigned long long)tiles_done);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+struct SelectArgs {
+    const float *P, *Q;
+    int64_t n;
+    int k;
+    const int32_t *users;
+    int64_t nu;
+    int N;
+    const int64_t *mask_ptr;
+    const int32_t *mask_idx;
+    int mask_by_user;
+    int32_t *ids;                // [nu][N] in: the lists so far (complete: N entries, scores descending); out: after the chunk
+    float *scores;
+    const uint32_t *masks;       // survivor words of the chunk, as k_scan_filter wrote them
+    int64_t mask_stride;
+    const uint32_t *summary;     // which words hold survivors
+    int64_t sum_stride;
+    int64_t item0, item1;
+    unsigned long long *work;    // slots as ScanArgs.work: [1] += state-machine events, [2] += exact scores computed
+    int true_topn;
+};
+
+constexpr int kSelKC = 32;           // floats of a row staged per pass
+constexpr int kSelLd = kSelKC + 4;   // staging row stride (floats): 16 lanes x 16 bytes fall on 64 different banks
+constexpr int kSelWin = 32;          // mask words whose survivors join the pending list at a time
+constexpr int kSelList = 64 + 32 * kSelWin;   // pending survivors: a rest below 64 plus one window's worth
+constexpr int kSelMaskCap = 256;     // masked (training) items of a user kept in LDS (longer rows: binary search in global memory)
+
+__host__ __device__ inline size_t select_wave_bytes() {
+    return 64 * kSelLd * sizeof(float) + 256 * sizeof(float) + kSelList * sizeof(int32_t) + kSelMaskCap * sizeof(int32_t);
+}
+__host__ __device__ inline size_t select_lds_bytes(int waves) { return (size_t)waves * select_wave_bytes(); }
+
+// One wave per user.  Any k <= 256 (rows are read in passes of kSelKC elements, zero beyond k).
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_scan_select(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned char *base = lds_raw + (size_t)w * select_wave_bytes();
+    float *stage = reinterpret_cast<float *>(base);                                  // [64][kSelLd]
+    float *prow_l = stage + 64 * kSelLd;                                             // [256] the user's row (zero beyond k)
+    int32_t *list = reinterpret_cast<int32_t *>(prow_l + 256);                       // [kSelList] pending survivors, ascending
+    int32_t *mrow = list + kSelList;                                                 // [kSelMaskCap]
+    const int64_t upos = (int64_t)blockIdx.x * WAVES + w;
+    if (upos >= a.nu) return;
+    const int k = a.k, N = a.N;
+    const int32_t uid = a.users[upos];
+    const float *prow = a.P + (int64_t)uid * k;
+    for (int e = lane; e < 256; e += 64) prow_l[e] = e < k ? prow[e] : 0.0f;
+    const int64_t mrow_id = a.mask_by_user ? (int64_t)uid : upos;
+    const int64_t m0 = a.mask_ptr[mrow_id], m1 = a.mask_ptr[mrow_id + 1];
+    const bool mask_in_lds = (m1 - m0) <= kSelMaskCap;
+    const int mcount = mask_in_lds ? (int)(m1 - m0) : 0;
+    for (int e = lane; e < mcount; e += 64) mrow[e] = a.mask_idx[m0 + e];
+    // the list, one slot per lane (N <= 64), scores descending
+    float sa = lane < N ? a.scores[upos * N + lane] : -INFINITY;
+    int32_t si = lane < N ? a.ids[upos * N + lane] : -1;
+    float thr = __shfl(sa, N - 1);
+    unsigned long long events = 0, exact = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    auto is_masked = [&](int32_t item) -> bool {
+        if (mask_in_lds) {
+            int lo = 0, hi = mcount;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; const int32_t v = mrow[mid]; if (v < item) lo = mid + 1; else hi = mid; }
+            return lo < mcount && mrow[lo] == item;
+        }
+        int64_t lo = m0, hi = m1;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; const int32_t v = a.mask_idx[mid]; if (v < item) lo = mid + 1; else hi = mid; }
+        return lo < m1 && a.mask_idx[lo] == item;
+    };
+    const bool vec_rows = (k & 3) == 0;
+    // elements [e0, e0 + 32) of the batch's rows: 8 lanes x 16 bytes per row, 8 rows per load instruction
+    auto gather = [&](const int32_t (&ritem)[8], int e0, f32x4 (&v)[8]) {
+        const int e = e0 + 4 * (lane & 7);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            v[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ritem[g] >= 0) {
+                const float *src = a.Q + (int64_t)ritem[g] * k + e;
+                if (vec_rows && e + 3 < k) v[g] = *reinterpret_cast<const f32x4 *>(src);
+                else { if (e < k) v[g][0] = src[0]; if (e + 1 < k) v[g][1] = src[1]; if (e + 2 < k) v[g][2] = src[2]; if (e + 3 < k) v[g][3] = src[3]; }
+            }
+        }
+    };
+    // exact scores of list[b0 .. b0 + 64) and the state machine on them
+    auto batch = [&](int b0, int count) {
+        const bool have = lane < count;
+        const int32_t item = have ? list[b0 + lane] : -1;
+        const bool live = have && !is_masked(item);
+        int32_t ritem[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { const int row = 8 * g + (lane >> 3); ritem[g] = row < count ? list[b0 + row] : -1; }
+        // acc = fma(P[e], Q[item][e], acc), e ascending (== score_chain of the oracle, == k_scores_one); the rows of the
+        // next pass are in flight while this pass is summed
+        float acc = 0.0f;
+        f32x4 v[8];
+        gather(ritem, 0, v);
+        for (int e0 = 0; e0 < k; e0 += kSelKC) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 8; ++g) *reinterpret_cast<f32x4 *>(stage + (8 * g + (lane >> 3)) * kSelLd + 4 * (lane & 7)) = v[g];
+            if (e0 + kSelKC < k) gather(ritem, e0 + kSelKC, v);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const float *qr = stage + lane * kSelLd;
+#pragma unroll
+            for (int e = 0; e < kSelKC; e += 4) {
+                const f32x4 pv = *reinterpret_cast<const f32x4 *>(prow_l + e0 + e);
+                const f32x4 qv = *reinterpret_cast<const f32x4 *>(qr + e);
+                acc = __builtin_fmaf(pv[0], qv[0], acc); acc = __builtin_fmaf(pv[1], qv[1], acc);
+                acc = __builtin_fmaf(pv[2], qv[2], acc); acc = __builtin_fmaf(pv[3], qv[3], acc);
+            }
+        }
+        exact += (unsigned long long)__popcll(__ballot(live));
+        // the state machine, candidates in ascending item order = ascending lane
+        unsigned long long cand = __ballot(live && thr < acc);
+        while (cand) {
+            const int l = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const float s = __shfl(acc, l);
+            if (!(thr < s)) continue;                                  // the threshold has risen meanwhile
+            const int32_t it = __shfl(item, l);
+            ++events;
+            // first slot strictly below s (slots with a[q] >= s come first: the list is sorted descending)
+            const int p = __popcll(__ballot(lane < N && sa >= s));
+            if (a.true_topn) {
+                // real top-N: insert with shift, the smallest entry drops out
+                const float up_a = __shfl_up(sa, 1);
+                const int32_t up_i = __shfl_up(si, 1);
+                if (lane > p && lane < N) { sa = up_a; si = up_i; }
+            }
+            if (lane == p) { sa = s; si = it; }
+            thr = __shfl(sa, N - 1);
+        }
+    };
+
+    const int64_t words = (a.item1 - a.item0 + kScanTile - 1) / kScanTile;
+    const int64_t swords = (words + 31) / 32;
+    const uint32_t *mw = a.masks + upos * a.mask_stride;
+    const uint32_t *sw = a.summary + upos * a.sum_stride;
+    int fill = 0;                                                      // pending survivors in list[0 .. fill)
+    // summary words 64 at a time (one per lane = 2,048 mask words = 65,536 items); the mask words with survivors are then
+    // fetched one per lane, 64 at a time, in ascending order
+    for (int64_t s0 = 0; s0 < swords; s0 += 64) {
+        uint32_t sword = (s0 + lane < swords) ? sw[s0 + lane] : 0u;
+        if (__ballot(sword != 0u) == 0ull) continue;
+        // number the set bits of the 64 summary words in ascending (lane, bit) order
+        const int scnt = __popc(sword);
+        int sincl = scnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(sincl, off); if (lane >= off) sincl += up; }
+        const int stotal = __shfl(sincl, 63);
+        const int sbase = sincl - scnt;
+        for (int t0 = 0; t0 < stotal; t0 += 64) {
+            // lane l takes the (t0 + l)-th word with survivors: find its owner lane (the one whose [sbase, sbase + scnt) holds it)
+            const int want = t0 + lane;
+            int owner = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) { const int cand_l = owner + step; const int b = __shfl(sbase, cand_l & 63); if (cand_l < 64 && b <= want) owner = cand_l; }
+            const uint32_t osw = __shfl(sword, owner);
+            const int obase = __shfl(sbase, owner);
+            uint32_t word = 0u;
+            int64_t widx = 0;
+            if (want < stotal) {
+                // the (want - obase)-th set bit of the owner's summary word
+                uint32_t bits = osw;
+                for (int q = want - obase; q > 0; --q) bits &= bits - 1;
+                widx = (s0 + owner) * 32 + (__ffs(bits) - 1);
+                word = mw[widx];
+            }
+            // survivors of these (up to 64) words behind the pending ones, ascending
+            const int cnt = __popc(word);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off); if (lane >= off) incl += up; }
+            const int total = __shfl(incl, 63);
+            // (64 words can hold 2,048 survivors: the list takes them in two halves of 32 words)
+            for (int half = 0; half < 2; ++half) {
+                const int lo_l = 32 * half;
+                const int before = half ? __shfl(incl, 31) : 0;
+                const int htotal = half ? total - before : __shfl(incl, 31);
+                if (htotal == 0) continue;
+                if (lane >= lo_l && lane < lo_l + 32) {
+                    int pos = fill + incl - cnt - before;
+                    const int32_t item_base = (int32_t)(a.item0 + widx * kScanTile);
+                    uint32_t bits = word;
+                    while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; list[pos++] = item_base + b; }
+                }
+                fill += htotal;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                int b0 = 0;
+                for (; fill - b0 >= 64; b0 += 64) batch(b0, 64);
+                if (b0) {                                              // the rest (< 64) moves to the front
+                    const int rest = fill - b0;
+                    const int32_t keep = lane < rest ? list[b0 + lane] : 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) list[lane] = keep;
+                    fill = rest;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (fill) batch(0, fill);
+    if (lane < N) { a.scores[upos * N + lane] = sa; a.ids[upos * N + lane] = si; }
+    if (lane == 0) { unsigned long long *wk = work_slot(a.work, (unsigned)upos); atomicAdd(wk + 1, events); atomicAdd(wk + 2, exact); }
+}
+
+}  // namespace yue

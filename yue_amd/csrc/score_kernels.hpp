@@ -23,6 +23,9 @@
 
 namespace yue {
 
+constexpr int kWorkSlots = 1024;
+__device__ __forceinline__ unsigned long long *work_slot(unsigned long long *work, unsigned wave_id) { return work + 4u * (wave_id & (kWorkSlots - 1)); }
+
 struct ScanArgs {
     const float *P, *Q;
     int64_t n;
@@ -36,8 +39,9 @@ struct ScanArgs {
     int32_t *out_ids;
     float *out_scores;
     int32_t *flags;        // [0] some user had < N candidates
-    unsigned long long *work; // [0] 32-user x 32-item tiles actually scored (the bf16 kernel skips tiles that cannot matter),
-                              // [1] state-machine events, [2] exact re-scores (bf16 path) -- 64-bit: 1.6e9 re-scores on a full config-5 scan
+    unsigned long long *work; // kWorkSlots x {[0] 32-user x 32-item tiles actually scored (the bf16 kernel skips tiles that cannot matter),
+                              // [1] state-machine events, [2] exact re-scores (bf16 path), [3] unused}: a wave adds to the slot of its
+                              // number (one counter for a million waves is 12 ns per add, in series); 64-bit: 1.6e9 re-scores on a full config-5 scan
     const float *tile_norm_max; // max ||Q[i]||_2 over each tile of 32 items (bf16 pre-filter margin); unused by the f32 kernel
     const float *tile_norm_sufmax; // max of tile_norm_max over this and all later tiles (early exit of the bf16 kernel)
     int true_topn;             // 0: the reference's overwrite-scan (default); 1: a real top-N (ties: lower id first)
@@ -99,7 +103,7 @@ __device__ __forceinline__ void scan_push(ScanState &S, int N, float s, int32_t 
     if (true_topn) scan_push_t<true>(S, N, s, item); else scan_push_t<false>(S, N, s, item);
 }
 
-__device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *flags, unsigned long long *work) {
+__device__ __forceinline__ void scan_finish(const ScanState &S, int N, int32_t *flags, unsigned long long *work) {      // work: the wave's slot
     if (S.cnt < N) {
         atomicOr(flags, 1);
         for (int q = 0; q < N; ++q) { S.g_sc[q] = -INFINITY; S.g_id[q] = -1; }
@@ -284,8 +288,9 @@ __global__ void __launch_bounds__(256) k_topn_scan(ScanArgs a) {
         __syncthreads();
     }
 
-    if (h == 0 && uvalid) scan_finish(S, N, a.flags, a.work);
-    if (lane == 0) atomicAdd(a.work, (unsigned long long)ntiles);
+    unsigned long long *wk = work_slot(a.work, blockIdx.x * kScanWaves + w);
+    if (h == 0 && uvalid) scan_finish(S, N, a.flags, wk);
+    if (lane == 0) atomicAdd(wk, (unsigned long long)ntiles);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -532,8 +537,9 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
         }
     }
 
-    if (h == 0 && uvalid) { scan_finish(S, N, a.flags, a.work); atomicAdd(a.work + 2, (unsigned long long)rescored); }
-    if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
+    unsigned long long *wk = work_slot(a.work, blockIdx.x * WAVES + w);
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags, wk); atomicAdd(wk + 2, (unsigned long long)rescored); }
+    if (lane == 0) atomicAdd(wk, (unsigned long long)tiles_done);
 }
 
 // Variant with TP tiles per loop iteration (one barrier per TP tiles): the MFMA chains of the iteration's tiles are
@@ -766,8 +772,9 @@ __global__ void __launch_bounds__(64 * WAVES, 512 / (64 * WAVES)) k_topn_scan_bf
         }
     }
 
-    if (h == 0 && uvalid) { scan_finish(S, N, a.flags, a.work); atomicAdd(a.work + 2, (unsigned long long)rescored); }
-    if (lane == 0) atomicAdd(a.work, (unsigned long long)tiles_done);
+    unsigned long long *wk = work_slot(a.work, blockIdx.x * WAVES + w);
+    if (h == 0 && uvalid) { scan_finish(S, N, a.flags, wk); atomicAdd(wk + 2, (unsigned long long)rescored); }
+    if (lane == 0) atomicAdd(wk, (unsigned long long)tiles_done);
 }
 
 template <int K16, int TP, int WAVES>
