@@ -135,7 +135,7 @@ def test_a_wave_that_cannot_get_its_row_gives_up_instead_of_hanging(dev):
 @pytest.mark.parametrize('m,n,d,k', [(3000, 2000, 20, 128), (5000, 64, 12, 64), (700, 900, 70, 10), (400, 300, 25, 200)])
 def test_two_wave_variant_is_bit_equal(dev, m, n, d, k):
     """Option chain_split: a run walked by a pair of waves (memory side / dependency chain, hand-over through LDS) must produce
-    exactly the factors and the loss of the one-wave kernel (70 events per user: runs longer than one segment of 64)."""
+    exactly the factors (and the loss) of the one-wave kernel (70 events per user: runs longer than one segment of 64)."""
     data, ev_u, P0, Q0 = _problem(m, n, d, k, 7)
     res = []
     for split in (0, 1):
@@ -149,4 +149,5 @@ def test_two_wave_variant_is_bit_equal(dev, m, n, d, k):
             dev.set_option('epoch_exact', 0)
             dev.set_option('chain_split', 0)
         res.append((nll,) + dev.get_factors())
-    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # (the loss is a sum of per-wave partials added in whatever order the waves finish)
+    assert abs(res[0][0] - res[1][0]) <= 1e-12 * abs(res[0][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
