@@ -13,6 +13,9 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
                                         throughput mode: counter-based sampler on the device,
                                         S-round semantics; -round N fixes the round size
                                         (auto = the device's default: yue_default_round_events, 172,032 events on MI355X for BASELINE config 3).
+  bpr.hip=-mode exact -seed 1           the device's counter-based sampler with the reference's EXACT sequential semantics (one dataflow
+                                        launch per epoch, chain_kernels.hpp): the loop of BPR.py:42-58 on other negatives than
+                                        Python's; needs no host sampling, so it also serves array-native data.
   bpr.hip=-mode adam                    the reference's LIVE path (BPR.py:65-129, a TensorFlow-1 graph): every "iteration" is one
                                         minibatch of 512 random training events x 100 rejection-sampled negatives (next_batch,
                                         :65-81, same NumPy / random calls), loss = sum softplus(-x) + regU * l2 terms, Adam(lRate)
@@ -124,10 +127,14 @@ class BPR(IterativeRecommender):
                 exit(-1)
             return self._build_adam()
         if isinstance(self.data, ArrayRecord) and opts['-mode'] == 'replay':
-            print('array-native data needs bpr.hip=-mode epoch (the replay mode samples over item names)')
+            print('array-native data needs bpr.hip=-mode epoch or exact (the replay mode samples over item names)')
+            exit(-1)
+        if opts['-mode'] not in ('replay', 'epoch', 'exact'):
+            print('bpr.hip: unknown -mode ' + opts['-mode'])
             exit(-1)
         self._sync_factors_to_device()
         dev, arr = self.dev, self._arrays
+        dev.set_option('epoch_exact', 1 if opts['-mode'] == 'exact' else 0)
         if opts['-mode'] == 'replay':
             ev_u = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(arr['ev_ptr']))
             listened_names = {user: {ev[self.recType] for ev in events} for user, events in self.data.userRecord.items()}
