@@ -402,10 +402,10 @@ def bench_fism(args, cp):
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64 (P, Bi) / f32 (Q)', 'data': 'synthetic',
         'config': {'workload': 'FISM: %d users x %d items, %d events/user, k=%d, rho=%d, alpha=%g, lr=%g, reg=%g, rounds of %d users; host work of a call '
-                               '(touched-item lists per user, upload of events and negatives) included in value' % (m, n, d, k, rho, alpha, lr, reg, round_users),
+                               '(upload of events and negatives) included in value' % (m, n, d, k, rho, alpha, lr, reg, round_users),
                    'final_half_sq_error': half,
                    'sequential_device_pass_draws_per_s': (nsl.stop - nsl.start) / seq_dt},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_fism_round<KR=%d> (one wave per user: latency of the user\'s chain of draws)' % (1 if k <= 64 else 2 if k <= 128 else 4),
+        'roofline': {'bound': 'hbm', 'kernel': 'k_fism_round_lds<KR=%d> (one wave per user, working rows in LDS: latency of the user\'s chain of draws)' % (1 if k <= 64 else 2 if k <= 128 else 4),
                      'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'algorithmic_bytes_per_draw': bytes_per_draw, 'traffic': None},
         'cpu_baseline': cpu}))
     dev.close()

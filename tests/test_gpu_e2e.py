@@ -164,6 +164,33 @@ def test_array_native_data_through_the_plugin_surface(tmp_path, capsys):
         assert a == b or abs(float(a.split(':')[1]) - float(b.split(':')[1])) < 1e-12
 
 
+def test_exact_mode_through_the_plugin_surface(tmp_path, capsys, orc):
+    """bpr.hip=-mode exact: array-native data, the device sampler's negatives, the reference's sequential semantics
+    (chain_kernels.hpp) -- the factors buildModel leaves equal the oracle's sequential loop on the same negatives, and the
+    printed loss lines follow from them."""
+    from yue_amd import synth
+    from yue_amd.data.arrays import ArrayRecord
+    from yue_amd.recommender.cf.BPR import BPR
+    m, n, d, k = 6000, 3000, 25, 64
+    data = synth.make_arrays(m, n, d, seed=19)
+    tp, ti = synth.make_test_arrays(m, n, d, 6, data['indptr'], data['indices'], seed=19)
+    conf = _c1_conf(tmp_path, k, 2, '10')
+    conf.config['bpr.hip'] = '-mode exact -seed 7 -gpu 0'
+    rec = BPR(conf, ArrayRecord(m, n, data['ev_ptr'], data['ev_i'], tp, ti))
+    np.random.seed(6)
+    rec.execute()
+    out = capsys.readouterr().out
+    assert 'BPR [1] iteration 2' in out
+    np.random.seed(6)
+    P = np.random.rand(m, k).astype(np.float32) / 10                 # IterativeRecommender.initModel's draws
+    Q = np.random.rand(n, k).astype(np.float32) / 10
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    for ep in range(2):                                                # (the bold driver changes the rate only after iteration 2)
+        j = orc.sample_counter(7, ep, ev_u, n, data['indptr'], data['indices'])
+        orc.bpr_sequential(P, Q, ev_u, data['ev_i'], j, 0.02, 0.01, 0.01)
+    assert np.abs(rec.P - P).max() <= 1e-6 * np.abs(P).max() and np.abs(rec.Q - Q).max() <= 1e-6 * np.abs(Q).max()
+
+
 def test_config2_through_the_driver_from_a_csr_file(tmp_path, capsys):
     """BASELINE config 2 (100K users x 50K items, k=64) from a binary csr data set through the reference's own entry:
     Config -> Yue(conf).execute() -> BPR.execute() (initModel, buildModel in epoch mode, evalRanking on ids)."""

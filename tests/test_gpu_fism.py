@@ -173,3 +173,36 @@ def test_through_the_plugin_surface(tmp_path, capsys):
     users = list(rec.data.testSet.keys())
     s = rec.predict(users[3])
     assert s.dtype == np.float64 and np.abs(s - z['predict16'][3]).max() < 1e-12
+
+
+@pytest.mark.parametrize('k', [64, 130, 10])
+def test_rounds_with_working_rows_in_lds_equal_the_global_form(dev, k):
+    # users of at most 64 touches take k_fism_round_lds (the wave finds its rows itself, working copies in LDS): same pass as
+    # k_fism_round (option fism_lds = 0) and as the NumPy oracle; ragged users, duplicates inside a user, repeated negatives
+    from oracle.numpy_fism import fism_rounds
+    rng = np.random.RandomState(11 + k)
+    n, rho, alpha = 50, 3, 0.5
+    sizes = [0, 1, 5, 12, 1, 16, 2, 0, 7, 9, 3, 16, 16]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev_i = np.concatenate([rng.randint(0, n // 2, s) for s in sizes]).astype(np.int32)
+    negs = []
+    for u, s in enumerate(sizes):
+        if s > 1:
+            mine = set(ev_i[ptr[u]:ptr[u + 1]].tolist())
+            negs += [int(rng.choice([x for x in range(n) if x not in mine])) for _ in range(s * rho)]
+    negs = np.array(negs, np.int32)
+    P0, Q0, B0 = rng.rand(n, k) / 100, (rng.rand(n, k) / 10).astype(np.float32), rng.rand(n) / 100
+    for round_users in (1, 5, 100):
+        res = []
+        for lds in (1, 0):
+            dev.set_option('fism_lds', lds)
+            dev.fism_set_model(P0, Q0, B0)
+            half, _, _, _ = dev.fism_rounds(ptr, ev_i, negs, rho, coefs(ptr, alpha), round_users, 0.02, 0.01, 0.03)
+            P, Q, Bi = np.empty_like(P0), np.empty_like(Q0), np.empty_like(B0)
+            dev.fism_get_model(P, Q, Bi)
+            res.append((half, P, Q, Bi))
+        dev.set_option('fism_lds', 1)
+        Po, Qo, Bo = P0.copy(), Q0.copy(), B0.copy()
+        half_o = fism_rounds(Po, Qo, Bo, ptr, ev_i, negs, rho, alpha, 0.02, 0.01, 0.03, round_users)
+        for half, P, Q, Bi in res:
+            assert rel_err(P, Po) < 1e-6 and rel_err(Bi, Bo) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(half - half_o) < 1e-6 * half_o, round_users

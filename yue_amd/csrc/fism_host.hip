@@ -98,6 +98,56 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
     for (int64_t u = 0; u < m; ++u) { const int64_t nu = user_ptr[u + 1] - user_ptr[u]; neg_ptr[(size_t)u + 1] = neg_ptr[(size_t)u] + (nu > 1 ? nu * rho : 0); }
     if (neg_ptr[(size_t)m] != n_negs) return fail(YUE_ERR_ARG, "yue_fism_rounds: need rho negatives per event of every user with more than one event (" + std::to_string(neg_ptr[(size_t)m]) + "), got " + std::to_string(n_negs));
     for (int64_t t = 0; t < n_negs; ++t) if (negs[t] < 0 || negs[t] >= c->fn) return fail(YUE_ERR_ARG, "yue_fism_rounds: negative item id out of range");
+    {
+        // Fast form (round 3): every user touches at most 64 rows and they fit in LDS -> k_fism_round_lds finds the rows itself;
+        // the host prepares nothing per user (the sorted item lists below took most of the call's time).
+        int64_t cnt_max = 0, ev_max = 1;
+        for (int64_t u = 0; u < m; ++u) { const int64_t nu = user_ptr[u + 1] - user_ptr[u]; if (nu > 1) cnt_max = std::max(cnt_max, nu + nu * rho); }
+        for (int64_t u0 = 0; u0 < m; u0 += round_users) ev_max = std::max(ev_max, user_ptr[std::min(m, u0 + round_users)] - user_ptr[u0]);
+        const size_t lds = (size_t)cnt_max * ((size_t)c->fk * 12 + 8);
+        if (c->opt_fism_lds && cnt_max >= 1 && cnt_max <= 64 && lds <= 64u * 1024u) {
+            const size_t nk = (size_t)c->fn * c->fk;
+            HIPCHK(c->f_negs.resize((size_t)std::max<int64_t>(n_negs, 1))); HIPCHK(c->f_neg_ptr.resize((size_t)m + 1)); HIPCHK(c->f_coef.resize((size_t)m));
+            HIPCHK(c->f_x.resize((size_t)ev_max * c->fk));
+            HIPCHK(c->f_dQ.resize(nk)); HIPCHK(c->f_dP.resize(nk)); HIPCHK(c->f_dB.resize((size_t)c->fn));
+            if (n_negs > 0) HIPCHK(hipMemcpyAsync(c->f_negs.p, negs, (size_t)n_negs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->f_neg_ptr.p, neg_ptr.data(), ((size_t)m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->f_coef.p, coef, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemsetAsync(c->f_dQ.p, 0, nk * sizeof(float), c->stream));
+            HIPCHK(hipMemsetAsync(c->f_dP.p, 0, nk * sizeof(double), c->stream));
+            HIPCHK(hipMemsetAsync(c->f_dB.p, 0, (size_t)c->fn * sizeof(double), c->stream));
+            double *sc = c->scal.p + yue_host::kNllSlotsHost;      // [0] half_sq, [1..3] sums of squares
+            HIPCHK(hipMemsetAsync(sc, 0, 4 * sizeof(double), c->stream));
+            yue::FismArgs a{};
+            a.P = c->fP.p; a.Q = c->fQ.p; a.Bi = c->fBi.p; a.n = c->fn; a.k = c->fk;
+            a.user_ptr = c->f_ptr.p; a.m = m; a.ev_i = c->f_items.p; a.negs = c->f_negs.p; a.rho = rho; a.coef = c->f_coef.p;
+            a.lr = lr; a.regI = regI; a.regB = regB; a.x_rows = c->f_x.p; a.out = sc;
+            yue::FismLdsArgs la{};
+            la.neg_ptr = c->f_neg_ptr.p; la.dQ = c->f_dQ.p; la.dP = c->f_dP.p; la.dB = c->f_dB.p; la.rows_cap = (int)cnt_max;
+            const void *kfn = kr_of(c->fk) == 1 ? (const void *)yue::k_fism_round_lds<1> : kr_of(c->fk) == 2 ? (const void *)yue::k_fism_round_lds<2> : (const void *)yue::k_fism_round_lds<4>;
+            HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const dim3 apply_grid((unsigned)std::min<int64_t>(1024, (int64_t)(nk + 255) / 256));
+            for (int64_t u0 = 0; u0 < m; u0 += round_users) {
+                const int64_t u1 = std::min(m, u0 + round_users);
+                la.u_begin = u0; la.u_end = u1;
+                const dim3 grid((unsigned)(u1 - u0));
+                switch (kr_of(c->fk)) {
+                    case 1: hipLaunchKernelGGL(yue::k_fism_round_lds<1>, grid, dim3(64), lds, c->stream, a, la); break;
+                    case 2: hipLaunchKernelGGL(yue::k_fism_round_lds<2>, grid, dim3(64), lds, c->stream, a, la); break;
+                    default: hipLaunchKernelGGL(yue::k_fism_round_lds<4>, grid, dim3(64), lds, c->stream, a, la); break;
+                }
+                hipLaunchKernelGGL(yue::k_fism_apply, apply_grid, dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->f_dP.p, c->f_dQ.p, c->f_dB.p, c->fn, c->fk);
+            }
+            hipLaunchKernelGGL(yue::k_fism_sumsq, dim3(256), dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, sc + 1);
+            HIPCHK(hipGetLastError());
+            double h[4];
+            HIPCHK(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (half_sq_out) *half_sq_out = h[0];
+            if (sumsq3_out) { sumsq3_out[0] = h[1]; sumsq3_out[1] = h[2]; sumsq3_out[2] = h[3]; }
+            return YUE_OK;
+        }
+    }
     std::vector<int32_t> uq_items, loc_i((size_t)std::max<int64_t>(E, 1)), loc_j((size_t)std::max<int64_t>(n_negs, 1)), tmp;
     for (int64_t u = 0; u < m; ++u) {
         tmp.assign(ev_i + user_ptr[u], ev_i + user_ptr[u + 1]);

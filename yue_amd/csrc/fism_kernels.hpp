@@ -271,6 +271,178 @@ __global__ void __launch_bounds__(256) k_fism_round(FismArgs a, FismRoundArgs ra
     if (lane == 0) atomicAdd(a.out, half_sq);
 }
 
+// The same round with the user's working rows in LDS (round 3): a wave finds the items its user touches itself (its events'
+// items and its negatives, at most 64 in all: one per lane; equal items share a row: first occurrence = the row's owner), copies
+// their rows into LDS, walks the reference's per-user loop there -- an LDS round trip per draw instead of an L2 one, and no host
+// work per user at all (k_fism_round takes sorted item lists and positions the host prepares) -- and adds (working row - round-start
+// row) into the difference buffers.  Same results as k_fism_round up to the order of the float atomics.
+struct FismLdsArgs {
+    int64_t u_begin, u_end;
+    const int64_t *neg_ptr;          // [m+1] first draw of user u in negs
+    float *dQ;
+    double *dP, *dB;
+    int rows_cap;                    // working rows a user may need (<= 64)
+};
+
+template <int KR>
+__global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fism_lds[];
+    const int lane = threadIdx.x;
+    const int64_t u = ra.u_begin + blockIdx.x;
+    if (u >= ra.u_end) return;
+    const int k = a.k;
+    const int64_t e0 = a.user_ptr[u], e1 = a.user_ptr[u + 1];
+    const int ne = (int)(e1 - e0);
+    if (ne <= 1) return;                                 // FISM.py:40-41
+    double *wp = reinterpret_cast<double *>(fism_lds);                               // [rows_cap][k]
+    double *wb = wp + (size_t)ra.rows_cap * k;                                       // [rows_cap]
+    float *wq = reinterpret_cast<float *>(wb + ra.rows_cap);                         // [rows_cap][k]
+    const float regI32 = (float)a.regI;
+    const int cnt = ne + ne * a.rho;                     // touches of this user (the host guarantees <= 64)
+    const int64_t n0 = ra.neg_ptr[u];
+    const int32_t x = lane < ne ? a.ev_i[e0 + lane] : lane < cnt ? a.negs[n0 + lane - ne] : -1;
+    int first = lane;                                    // lowest lane holding the same item
+    for (int t = 0; t < cnt; ++t) { const int32_t xt = __builtin_amdgcn_readlane(x, t); if (lane < cnt && x == xt && t < first) first = t; }
+    const unsigned long long fmask = __ballot(lane < cnt && first == lane);
+    const int urow = __popcll(fmask & ((1ull << first) - 1ull));                    // the item's working row
+    const int nuniq = __popcll(fmask);
+    {   // copy in the rows this user touches, eight rows' loads in flight at a time
+        unsigned long long mleft = fmask;
+        for (int s0 = 0; s0 < nuniq; s0 += 8) {
+            int64_t it[8];
+            float q[8][KR];
+            double p[8][KR], b[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int src = mleft ? __ffsll((long long)mleft) - 1 : 0;
+                mleft &= mleft - 1;
+                it[t] = __builtin_amdgcn_readlane(x, src);
+                const bool ex = s0 + t < nuniq;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int el = 64 * r + lane;
+                    q[t][r] = (ex && el < k) ? a.Q[it[t] * k + el] : 0.0f;
+                    p[t][r] = (ex && el < k) ? a.P[it[t] * k + el] : 0.0;
+                }
+                b[t] = ex ? a.Bi[it[t]] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (s0 + t < nuniq) {
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) { wq[(s0 + t) * k + el] = q[t][r]; wp[(s0 + t) * k + el] = p[t][r]; } }
+                    if (lane == 0) wb[s0 + t] = b[t];
+                }
+            }
+        }
+    }
+    double *xr = a.x_rows + (e0 - a.user_ptr[ra.u_begin]) * k;
+    const double coef = a.coef[u];
+    double hist[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) hist[r] = 0.0;
+    for (int e = 0; e < ne; ++e) {                       // :44-46
+        const int s = __builtin_amdgcn_readlane(urow, e);
+#pragma unroll
+        for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) hist[r] = hist[r] + wp[s * k + el]; }
+    }
+    double half_sq = 0.0;
+    for (int e = 0; e < ne; ++e) {
+        const int i = __builtin_amdgcn_readlane(urow, e);
+        double xs[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) xs[r] = 0.0;
+        for (int c = 0; c < a.rho; ++c) {
+            const int j = __builtin_amdgcn_readlane(urow, ne + e * a.rho + c);
+            double di[KR], dj[KR];
+            float qi[KR], qj[KR];
+            double ai = 0.0, aj = 0.0;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int el = 64 * r + lane;
+                di[r] = dj[r] = 0.0; qi[r] = qj[r] = 0.0f;
+                if (el < k) { di[r] = hist[r] - wp[i * k + el]; dj[r] = hist[r] - wp[j * k + el]; qi[r] = wq[i * k + el]; qj[r] = wq[j * k + el]; }
+                const double m1 = di[r] * (double)qi[r]; ai = ai + m1;
+                const double m2 = dj[r] * (double)qj[r]; aj = aj + m2;
+            }
+            const double bi = wb[i], bj = wb[j];
+            const double r_pos = coef * wave_sum_f64(ai) + bi;          // :54
+            const double r_neg = coef * wave_sum_f64(aj) + bj;          // :55
+            const double err = 1.0 - (r_pos - r_neg);
+            half_sq = half_sq + 0.5 * (err * err);                      // :58
+            __builtin_amdgcn_wave_barrier();                            // (every lane has read the two biases)
+            if (lane == 0) {
+                wb[i] = bi + a.lr * (err - a.regB * bi);                // :59
+                wb[j] = bj - a.lr * (err + a.regB * bj);                // :60
+            }
+            const double ec = err * coef;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int el = 64 * r + lane;
+                const float ri = regI32 * qi[r], rj = regI32 * qj[r];
+                const float ni = (float)((double)qi[r] + a.lr * (ec * di[r] - (double)ri));     // :61
+                const float nj = (float)((double)qj[r] - a.lr * (ec * dj[r] + (double)rj));     // :62
+                const float dq = ni - nj;
+                xs[r] = xs[r] + err * (double)dq;                                                // :63
+                if (el < k) { wq[i * k + el] = ni; wq[j * k + el] = nj; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) xr[(int64_t)e * k + el] = xs[r]; }
+    }
+    const double pc = 1.0 / (double)a.rho * coef;                       // :68, left to right
+    for (int e = 0; e < ne; ++e) {
+        const int s = __builtin_amdgcn_readlane(urow, e);
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int el = 64 * r + lane;
+            if (el < k) { const double p = wp[s * k + el]; wp[s * k + el] = p + a.lr * (pc * xr[(int64_t)e * k + el] - a.regI * p); }
+        }
+    }
+    {   // what this user changed: working row - round-start row, added to the round's difference buffers (the round-start rows
+        // again eight at a time)
+        unsigned long long mleft = fmask;
+        for (int s0 = 0; s0 < nuniq; s0 += 8) {
+            int64_t it[8];
+            float q[8][KR];
+            double p[8][KR], b[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int src = mleft ? __ffsll((long long)mleft) - 1 : 0;
+                mleft &= mleft - 1;
+                it[t] = __builtin_amdgcn_readlane(x, src);
+                const bool ex = s0 + t < nuniq;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int el = 64 * r + lane;
+                    q[t][r] = (ex && el < k) ? a.Q[it[t] * k + el] : 0.0f;
+                    p[t][r] = (ex && el < k) ? a.P[it[t] * k + el] : 0.0;
+                }
+                b[t] = ex ? a.Bi[it[t]] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (s0 + t < nuniq) {
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) {
+                        const int el = 64 * r + lane;
+                        if (el < k) {
+                            const float dq = wq[(s0 + t) * k + el] - q[t][r];
+                            if (dq != 0.0f) atomicAdd(ra.dQ + it[t] * k + el, dq);
+                            const double dp = wp[(s0 + t) * k + el] - p[t][r];
+                            if (dp != 0.0) atomicAdd(ra.dP + it[t] * k + el, dp);
+                        }
+                    }
+                    if (lane == 0) { const double db = wb[s0 + t] - b[t]; if (db != 0.0) atomicAdd(ra.dB + it[t], db); }
+                }
+            }
+        }
+    }
+    if (lane == 0) atomicAdd(a.out, half_sq);
+}
+
 // end of a round: model += summed differences, buffers cleared
 __global__ void __launch_bounds__(256) k_fism_apply(double *P, float *Q, double *Bi, double *dP, float *dQ, double *dB, int64_t n, int k) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, tot = n * k;

@@ -124,6 +124,7 @@ struct yue_ctx {
     DevBuf<double> f_wp, f_wb, f_dP, f_dB;
     int64_t fn = 0;
     int fk = 0;
+    int opt_fism_lds = 1;                // 0: yue_fism_rounds always through k_fism_round (working rows in global memory, item lists from the host)
     // exact path (chain_host.hip): touch keys / ordinals, runs, granule copies of the factor rows, control words
     DevBuf<uint32_t> ch_key, ch_val, ch_key2, ch_val2, ch_seg, ch_ord_i, ch_ord_j, ch_head, ch_incl, ch_ord_u, ch_rkey, ch_rval;
     DevBuf<int64_t> ch_run_ptr, d_ev_ptr;

@@ -298,9 +298,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_scan_select(SelectArgs a) {
         while (cand) {
             const int l = __ffsll((long long)cand) - 1;
             cand &= cand - 1;
-            const float s = __shfl(acc, l);
+            // (l is wave-uniform: v_readlane, a few cycles, instead of a trip through the LDS crossbar per value)
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), l));
             if (!(thr < s)) continue;                                  // the threshold has risen meanwhile
-            const int32_t it = __shfl(item, l);
+            const int32_t it = __builtin_amdgcn_readlane(item, l);
             ++events;
             // first slot strictly below s (slots with a[q] >= s come first: the list is sorted descending)
             const int p = __popcll(__ballot(lane < N && sa >= s));
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_scan_select(SelectArgs a) {
                 if (lane > p && lane < N) { sa = up_a; si = up_i; }
             }
             if (lane == p) { sa = s; si = it; }
-            thr = __shfl(sa, N - 1);
+            thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sa), N - 1));
         }
     };
 
