@@ -84,13 +84,15 @@ def test_round_kernels_fit_the_residency_the_host_assumes(tmp_path):
         m = re.search(r'remark:\s+(TotalSGPRs|VGPRs|ScratchSize \[bytes/lane\]): (\d+)', line)
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
-    # the instantiations the default events-per-wave choice launches: k <= 64 -> <1,16>, k <= 128 -> <2,8>, else <4,4>
+    # the instantiations the default events-per-wave choice launches: k_round_m k <= 64 -> <1,8>, k <= 128 -> <2,8>, else <4,4>;
+    # k_round <1,16>, <2,8>, <4,4>
     seen = 0
     for fn, u in usage.items():
-        for kr, tpw in ((1, 16), (2, 8), (4, 4)):
+        for kr, tpw in ((1, 8), (2, 8), (4, 4)):
             if 'k_round_mILi%dELi%dEE' % (kr, tpw) in fn:
                 assert u['TotalSGPRs'] <= 96 and u['VGPRs'] <= 72 and u['ScratchSize [bytes/lane]'] == 0, (fn, u)
                 seen += 1
+        for kr, tpw in ((1, 16), (2, 8), (4, 4)):
             if '7k_roundILi%dELi%dEE' % (kr, tpw) in fn:
                 assert u['TotalSGPRs'] <= 112 and u['VGPRs'] <= 80 + 8 * (kr == 4) and u['ScratchSize [bytes/lane]'] == 0, (fn, u)
                 seen += 1

@@ -202,10 +202,11 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
     rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     j = orc.sample_counter(9, 0, ev_u, n, data['indptr'], data['indices'])
     nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
-    # (with round_meta 1 also 2..4: staged up to that many touches per row);
+    # (with round_meta 1 also 2..64: staged up to that many touches per row -- W = 8,192 events on 2,500 items: 6.5
+    # touches per row and round on average, blocks of every size up to 64 occur);
     # round_meta: touch metadata from the per-epoch pre-pass + fold launches (default) vs touches counted and contended
     # rows finished inside the round launches
-    for tpw, stage, meta in [(0, 1, 1), (0, 0, 1), (4, 1, 1), (2, 0, 1), (0, 2, 1), (8, 3, 1), (0, 1, 0), (0, 0, 0), (4, 1, 0)]:
+    for tpw, stage, meta in [(0, 1, 1), (0, 0, 1), (4, 1, 1), (2, 0, 1), (0, 2, 1), (8, 3, 1), (0, 7, 1), (4, 13, 1), (0, 64, 1), (0, 1, 0), (0, 0, 0), (4, 1, 0)]:
         dev = Device(0, raise_errors=True)
         dev.set_option('round_tpw', tpw)
         dev.set_option('round_stage', stage)
@@ -293,11 +294,11 @@ def test_default_round_size_is_one_resident_wave_set(orc):
 
 
 def test_default_round_size_grows_with_the_item_count():
-    # epoch path: up to 3 resident sets of the update kernel, as long as a round holds at most one event per item row
+    # epoch path: up to 6 resident sets of the update kernel, as long as a round holds at most four events per item row
     from yue_amd._shim import Device
     k = 128
     sizes = {}
-    for n in (1000, 130000, 200000, 400000):
+    for n in (1000, 20000, 130000, 200000, 400000):
         dev = Device(0, raise_errors=True)
         dev.set_factors(np.zeros((8, k), np.float32), np.zeros((n, k), np.float32))
         sizes[n] = dev.default_round_events()
@@ -308,7 +309,10 @@ def test_default_round_size_grows_with_the_item_count():
         dev.close()
     one = sizes[1000]
     assert one % 1024 == 0
-    assert sizes[130000] == one * min(3, 130000 // one) and sizes[200000] == one * min(3, 200000 // one) and sizes[400000] == 3 * one
+    for n in (20000, 130000, 200000, 400000):
+        sets = min(6, max(1, 4 * n // one))
+        assert sizes[n] == one * (min(sets, 4) if one * sets < n else sets), (n, sizes)     # (wide catalogues: at most 4 sets)
+    assert sizes[400000] == 4 * one and sizes[200000] == 6 * one
     dev = Device(0, raise_errors=True)                           # large catalogues: bucketed pre-pass, still the epoch path ...
     dev.set_factors(np.zeros((8, 4), np.float32), np.zeros((500000, 4), np.float32))
     assert dev.get_option('round_path') == 1

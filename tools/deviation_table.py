@@ -32,6 +32,8 @@ def main():
     dev = Device(0, raise_errors=True)
     dev.set_factors(P0, Q0)
     dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    for kv in filter(None, os.environ.get('YUE_OPTS', '').split(',')):      # tuning options of the S-round path (timing only)
+        dev.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     E = int(data['ev_ptr'][-1])
     rounds = [int(x) for x in sys.argv[2:]] or [8192, 57344, 114688, 172032]
     dev.set_option('epoch_exact', 1)

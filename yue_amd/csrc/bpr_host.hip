@@ -38,12 +38,13 @@ void launch_level(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1) {
     }
 }
 
-int tpw_of(const yue_ctx *c) {
+// `meta`: for k_round_m (update launch on pre-pass metadata) instead of k_round
+int tpw_of(const yue_ctx *c, bool meta) {
     if (c->opt_round_tpw) return c->opt_round_tpw;
-    // measured: k = 128 (C3): 8 events per wave 53.9 ms/epoch, 4 -> 58.7, 16 -> 60.7; k = 64 (C2, half the row registers):
-    // 16 events per wave 5.2 ms/epoch, 8 -> 5.7
+    // measured: k = 128 (C3): 8 events per wave 53.9 ms/epoch, 4 -> 58.7, 16 -> 60.7; k = 64 (C2): k_round 16 events per wave
+    // 5.2 ms/epoch, 8 -> 5.7; k_round_m + fold (round 3, profiles/r03_round_w_stage_sweep.txt) 8 -> 3.0 ms, 16 -> 3.3
     const int kr = kr_of(c->k);
-    return kr == 4 ? 4 : kr == 2 ? 8 : 16;
+    return kr == 4 ? 4 : kr == 2 ? 8 : meta ? 8 : 16;
 }
 
 // Epoch path: the pre-pass over all rounds (k_round_meta) -- one LDS word per item row of a range, ranges of at most
@@ -51,7 +52,8 @@ int tpw_of(const yue_ctx *c) {
 // stays on k_round (touches counted inside the round launches).
 constexpr int64_t kMetaRangeMax = 37 * 1024;       // 148 KB of the CU's 160 KB of LDS
 constexpr int64_t kMetaRangesMax = 12;
-constexpr int64_t kRoundGenerationsMax = 3;
+constexpr int64_t kRoundGenerationsMax = 6;
+constexpr double kRoundEventsPerItemRow = 4.0;
 
 // Larger catalogues (up to kBucketRangesMax ranges of 2^kBucketShift rows = 8.4M item rows per GPU) sort a round's touches into
 // their ranges first (k_round_bucket), so that a work item reads its own touches only.
@@ -64,12 +66,15 @@ bool fold_path(const yue_ctx *c) { return meta_path_fits(c); }
 //     of 4 waves x TPW events) -- a launch is a single wave generation, the measured optimum of a kernel whose waves wait
 //     for each other (49,152 at k = 128);
 //   * the fold path (k_round_m without retire + k_round_fold: no wave waits for another): up to kRoundGenerationsMax
-//     resident sets, as long as a round stays at or below one event per item row (at most ~2 touches of a row per round:
-//     the staleness of the S-round semantics is bounded relative to the item count) -- 3 x 57,344 on C3.
+//     resident sets, as long as a round stays at or below kRoundEventsPerItemRow events per item row (the staleness of
+//     the S-round semantics is bounded relative to the item count) -- 6 x 57,344 = 344,064 on C3, 3 x 57,344 on C2.
+//     Round 3 measured (profiles/r03_deviation_*.jsonl): the distance from the sequential loop is
+//     set by a user's events sharing one round, not by W -- C3: loss +0.320 % at W = 172,032, +0.332 % at 344,064;
+//     rounds of 6 sets with staging blocks sized for them are 6 % faster than rounds of 3.
 // `n_rows` = item rows per rank (job-wide average on a communicator, so that all ranks agree).
 int default_round_events(yue_ctx *c, double n_rows, int64_t *out) {
-    const int tpw = tpw_of(c);
     const bool fold = fold_path(c);
+    const int tpw = tpw_of(c, fold);
     int per_cu = 0, cus = 0;
     hipError_t e = hipSuccess;
 #define YUE_OCC(KR_, TPW_) \
@@ -99,7 +104,14 @@ int default_round_events(yue_ctx *c, double n_rows, int64_t *out) {
     int64_t w = (int64_t)(slots * 4.0 * tpw);
     w -= w % 1024;
     w = std::max<int64_t>(w, 1024);
-    if (fold) w *= std::min<int64_t>(kRoundGenerationsMax, std::max<int64_t>(1, (int64_t)(n_rows / (double)w)));
+    if (fold) {
+        int64_t sets = std::min<int64_t>(kRoundGenerationsMax, std::max<int64_t>(1, (int64_t)(kRoundEventsPerItemRow * n_rows / (double)w)));
+        // wide catalogues (fewer than two touches per item row and round): nearly every row is written in place, a larger
+        // round amortises nothing and the rows it writes outgrow the memory-side cache (measured on c3wide, 1M item rows:
+        // 29.4 ms/epoch at 3 and 4 sets, 31.6 at 6)
+        if (2.0 * (double)(w * sets) < 2.0 * n_rows) sets = std::min<int64_t>(sets, 4);
+        w *= sets;
+    }
     *out = w;
     return YUE_OK;
 }
@@ -116,7 +128,7 @@ int launch_round(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1,
     uint32_t *tab[2] = {c->tab0.p, c->tab1.p};
     ra.tab_cur = tab[parity]; ra.tab_next = tab[parity ^ 1]; ra.staged = c->staged ? 1 : 0;
     ra.apply_p = apply_p;
-    const int tpw = tpw_of(c);
+    const int tpw = tpw_of(c, false);
     const int64_t waves = (std::max(e1 - e0, n1 - n0) + tpw - 1) / tpw;      // every wave: tickets of the next round + its update batch
     const int64_t blocks = (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
@@ -178,7 +190,17 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
         ma.range = (int32_t)((c->n + ma.G - 1) / ma.G);
     }
     ma.chunk = (ma.range + 1023) / 1024; ma.chunk |= 1;
-    ma.stage_max = !c->staged ? 1u : c->opt_round_stage >= 2 ? (uint32_t)c->opt_round_stage : yue::kMetaStageMax;
+    // Largest staged block: rows with more touches take float atomics (executed memory-side on this chip, ~1 TB/s) -- sized
+    // from the round's mean touches per item row so that the blocks cover the bulk of the distribution; a block is summed
+    // by one wave of the fold launch, very long ones would be its tail.  Measured per k (profiles/r03_round_w_stage_sweep.txt):
+    // k <= 64 (rows of 256 B: an atomic row costs as many requests as bytes/64) 4 x the mean, else 2 x.
+    int64_t widest = 0;
+    for (int64_t r = 0; r < R; ++r) widest = std::max(widest, bounds[(size_t)r + 1] - bounds[(size_t)r]);
+    const double mean_touches = 2.0 * (double)widest / (double)std::max<int64_t>(1, c->n);
+    const uint32_t stage_auto = (uint32_t)std::min<double>((double)yue::kMetaStageMax, std::max<double>((double)yue::kMetaStageDefault,
+                                                         std::ceil(mean_touches * (kr_of(c->k) == 1 ? 4.0 : 2.0))));
+    ma.stage_max = !c->staged ? 1u : c->opt_round_stage >= 2 ? (uint32_t)c->opt_round_stage : stage_auto;
+    c->last_stage_max = (int)ma.stage_max;
     ma.meta_i = c->meta_i.p; ma.meta_j = c->meta_j.p; ma.round_rows = c->round_rows.p; ma.fold = c->fold.p;
     const size_t lds = (size_t)ma.range * sizeof(uint32_t);
     const void *kfn = bucketed ? (const void *)yue::k_round_meta<true> : (const void *)yue::k_round_meta<false>;
@@ -199,7 +221,7 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
 int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t round_index) {
     yue::RoundMArgs ra{};
     ra.e_begin = e0; ra.e_end = e1; ra.staged = c->staged ? 1 : 0;
-    const int tpw = tpw_of(c);
+    const int tpw = tpw_of(c, true);
     const int64_t waves = (e1 - e0 + tpw - 1) / tpw;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks == 0) return YUE_OK;
@@ -437,7 +459,7 @@ int yue_bpr_rounds(yue_ctx *c, const int32_t *u, const int32_t *i, const int32_t
     for (int64_t r = 0; r < n_rounds; ++r) if (round_ptr[r + 1] < round_ptr[r]) return fail(YUE_ERR_ARG, "yue_bpr_rounds: round_ptr must be non-decreasing");
     if (c->m * (int64_t)c->k * 4 >= (1ll << 31)) {
         // the round kernel addresses P relative to the smallest user of a wave's batch with 31-bit offsets
-        const int tpw = tpw_of(c);
+        const int tpw = tpw_of(c, false);
         for (int64_t r = 0; r < n_rounds; ++r)
             for (int64_t b = round_ptr[r]; b < round_ptr[r + 1]; b += tpw) {
                 int32_t lo = u[b], hi = u[b];
@@ -714,6 +736,7 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "scan_last_chunks") *value = c->scan_chunks;
     else if (key == "topn_true") *value = c->opt_topn_true;
     else if (key == "round_stage") *value = c->opt_round_stage;
+    else if (key == "round_last_stage_max") *value = c->last_stage_max;
     else if (key == "round_meta") *value = c->opt_round_meta;
     else if (key == "round_bucket") *value = c->opt_round_bucket;
     else if (key == "fold_blocks") *value = c->opt_fold_blocks;
@@ -742,7 +765,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "fism_lds") { c->opt_fism_lds = value != 0; return YUE_OK; }
     if (key == "scan_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(YUE_ERR_ARG, "yue_set_option: scan_growth must be 0 (automatic) or 2..64"); c->opt_scan_growth = (int)value; return YUE_OK; }
     if (key == "round_stage") {
-        if (value < 0 || value > (int64_t)yue::kMetaStageMax) return fail(YUE_ERR_ARG, "yue_set_option: round_stage must be 0, 1 or 2..4");
+        if (value < 0 || value > (int64_t)yue::kMetaStageMax) return fail(YUE_ERR_ARG, "yue_set_option: round_stage must be 0, 1 or 2..64");
         c->opt_round_stage = (int)value; return YUE_OK;
     }
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }

@@ -44,17 +44,20 @@
 namespace yue {
 
 // Metadata word of one touch (an event's positive or negative item row) in its round:
-//   bits 0..3   class: 0 no touch (the sampler gave up on the event), 1 the round's only touch of the row,
-//               2..kMetaStageMax touches -> staged, kMetaHot hotter -> float atomics into dQ
-//   bits 4..6   staged: this touch's ticket on its row (0 .. class - 1; room for blocks of up to 8 rows)
-//   bits 7..31  staged: first staging row of the row's block (the block is `class` consecutive rows);
-//               hot: the row's number of touches in the round
-constexpr uint32_t kMetaStageMax = 4u;   // measured on C3: staging rows with 5..8 touches too is slower (34.0 vs 33.2 ms/epoch)
-constexpr uint32_t kMetaHot = 15u;
+//   bits 0..1   kind: 0 no touch (the sampler gave up on the event), 1 the round's only touch of the row (stored in place),
+//               2 staged (the row has 2..stage_max touches), 3 hot (hotter: float atomics into dQ)
+//   bits 2..31  staged: THIS touch's staging row (first row of the row's block + the touch's ticket)
+// Fold-list word of a contended row:
+//   bits 25..31 staged: the row's touches = rows of its block (2..kMetaStageMax); 0: hot
+//   bits 0..24  staged: first staging row of the block
+constexpr uint32_t kMetaStageMax = 64u;  // largest block (7-bit count field)
+constexpr uint32_t kMetaStageDefault = 4u;   // measured on C3 (k = 128): staging rows with 5..8 touches too is slower (34.0 vs 33.2 ms/epoch)
+constexpr uint32_t kMetaUnique = 1u, kMetaStaged = 2u, kMetaHot = 3u;
 constexpr int kMetaUnroll = 8;       // events per thread and step of k_round_meta's two sweeps (their loads are in flight together)
-__host__ __device__ inline uint32_t meta_class(uint32_t w) { return w & 15u; }
-__host__ __device__ inline uint32_t meta_ticket(uint32_t w) { return (w >> 4) & 7u; }
-__host__ __device__ inline uint32_t meta_payload(uint32_t w) { return w >> 7; }
+__host__ __device__ inline uint32_t meta_kind(uint32_t w) { return w & 3u; }
+__host__ __device__ inline uint32_t meta_slot(uint32_t w) { return w >> 2; }
+__host__ __device__ inline uint32_t fold_count(uint32_t w) { return w >> 25; }
+__host__ __device__ inline uint32_t fold_block(uint32_t w) { return w & 0x1ffffffu; }
 
 struct MetaArgs {
     const int32_t *ev_i, *ev_j;
@@ -69,7 +72,7 @@ struct MetaArgs {
     // [R] per round, zeroed before the launch: low half = staging rows handed out, high half = contended rows listed
     unsigned long long *round_rows;
     // Fold list: the contended rows of round r are fold[fold_base(bounds[r], r) ...), (round_rows[r] >> 32) of them --
-    // {item row, metadata word with ticket 0} each; a round has at most as many contended rows as events.
+    // {item row, fold-list word} each; a round has at most as many contended rows as events.
     uint2 *fold;
     // Large catalogues (more ranges than a work item should re-read its round for): the round's touches, bucketed by item
     // range by k_round_bucket -- {item row, 2 * (event - first event of the round) + (0 positive | 1 negative)} each, the
@@ -160,10 +163,10 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
             if (s < width) {
                 const uint32_t c = slots[s];
                 if (c >= 2u) {
-                    const uint32_t wd = c <= a.stage_max ? (c | ((uint32_t)run << 7)) : (kMetaHot | (c << 7));
-                    slots[s] = wd;
-                    fold[run >> 32] = make_uint2((uint32_t)(lo + s), wd);
-                    run += (1ull << 32) + (c <= a.stage_max ? c : 0u);
+                    const bool st = c <= a.stage_max;
+                    slots[s] = st ? (kMetaStaged | ((uint32_t)run << 2)) : kMetaHot;
+                    fold[run >> 32] = make_uint2((uint32_t)(lo + s), st ? ((c << 25) | ((uint32_t)run & 0x1ffffffu)) : 0u);
+                    run += (1ull << 32) + (st ? c : 0u);
                 }
             }
         }
@@ -173,8 +176,8 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
             for (uint32_t t = tid; t < mine_n; t += 1024) {
                 const uint2 tc = mine_t[t];
                 const uint32_t sl = tc.x - (uint32_t)lo;
-                const uint32_t wd = slots[sl], cl = meta_class(wd);
-                const uint32_t mw = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[sl], 16u) : wd;
+                const uint32_t wd = slots[sl];
+                const uint32_t mw = meta_kind(wd) == kMetaStaged ? atomicAdd(&slots[sl], 4u) : wd;
                 ((tc.y & 1u) ? a.meta_j : a.meta_i)[e0 + (tc.y >> 1)] = mw;
             }
         } else
@@ -190,15 +193,14 @@ __global__ void __launch_bounds__(1024) k_round_meta(MetaArgs a) {
                 const int64_t e = eb + 1024 * q;
                 if (vj[q] >= 0) {
                     const uint32_t si = (uint32_t)(vi[q] - lo), sj = (uint32_t)(vj[q] - lo);
-                    // a staged row's word hands out the tickets: the adds of its `class` touches leave the fields
-                    // a reader needs intact (the last one may carry into the block field, nobody reads it afterwards)
+                    // a staged row's word hands out the block's rows: every touch takes the next one
                     if (si < (uint32_t)width) {
-                        const uint32_t wd = slots[si], cl = meta_class(wd);
-                        a.meta_i[e] = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[si], 16u) : wd;
+                        const uint32_t wd = slots[si];
+                        a.meta_i[e] = meta_kind(wd) == kMetaStaged ? atomicAdd(&slots[si], 4u) : wd;
                     }
                     if (sj < (uint32_t)width) {
-                        const uint32_t wd = slots[sj], cl = meta_class(wd);
-                        a.meta_j[e] = (cl >= 2u && cl < kMetaHot) ? atomicAdd(&slots[sj], 16u) : wd;
+                        const uint32_t wd = slots[sj];
+                        a.meta_j[e] = meta_kind(wd) == kMetaStaged ? atomicAdd(&slots[sj], 4u) : wd;
                     }
                 } else if (g == 0 && e < e1) {
                     a.meta_i[e] = 0u; a.meta_j[e] = 0u;
@@ -386,12 +388,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float c = rdlane(cs, t);
-        const unsigned cli = meta_class(hmi[t]), clj = meta_class(hmj[t]);
-        const bool uniq_i = cli == 1u, uniq_j = clj == 1u;
-        const bool hot_i = cli >= kMetaHot, hot_j = clj >= kMetaHot;
-        // where the row's store goes: the row itself (only touch of the round) or the touch's staging row (block + ticket)
-        const unsigned wi = uniq_i ? oi[t] : stage0 + (meta_payload(hmi[t]) + meta_ticket(hmi[t])) * row_bytes;
-        const unsigned wj = uniq_j ? oj[t] : stage0 + (meta_payload(hmj[t]) + meta_ticket(hmj[t])) * row_bytes;
+        const unsigned cli = meta_kind(hmi[t]), clj = meta_kind(hmj[t]);
+        const bool uniq_i = cli == kMetaUnique, uniq_j = clj == kMetaUnique;
+        const bool hot_i = cli == kMetaHot, hot_j = clj == kMetaHot;
+        // where the row's store goes: the row itself (only touch of the round) or the touch's staging row
+        const unsigned wi = uniq_i ? oi[t] : stage0 + meta_slot(hmi[t]) * row_bytes;
+        const unsigned wj = uniq_j ? oj[t] : stage0 + meta_slot(hmj[t]) * row_bytes;
         if (ok[t]) {                                     // wave-uniform
             run_ok = true;
             Elem o[KR];
@@ -450,34 +452,37 @@ struct FoldArgs {
 template <int KR, int EPG>
 __device__ __forceinline__ void fold_group(const FoldArgs &f, int lane, unsigned k, uint32_t nact, const uint2 (&ent)[4]) {
     // straight-line loads (no wait between the entries): the first two rows of a block always (a hot row reads its row of
-    // dQ), rows 2..3 behind a wave-uniform branch on the row's touch count; lanes beyond k read element k - 1
-    float x[EPG][KR], st[EPG][kMetaStageMax][KR];
+    // dQ), rows 2..3 behind a wave-uniform branch on the row's touch count; lanes beyond k read element k - 1.  Larger
+    // blocks (rows 4..) are summed behind the stores of the group, four rows at a time.
+    float x[EPG][KR], st[EPG][4][KR];
     unsigned el[KR];
+    bool big = false;
 #pragma unroll
     for (int r = 0; r < KR; ++r) el[r] = min(64u * r + lane, k - 1u);
 #pragma unroll
     for (int sl = 0; sl < EPG; ++sl) {
         if ((uint32_t)sl >= nact) continue;
-        const uint32_t c = meta_class(ent[sl].y);
-        const bool hot = c >= kMetaHot;
+        const uint32_t c = fold_count(ent[sl].y);
+        const bool hot = c == 0u;
         const float *row = f.Q + (uint64_t)ent[sl].x * k;
-        const float *src = hot ? f.dQ + (uint64_t)ent[sl].x * k : f.stage + (uint64_t)meta_payload(ent[sl].y) * k;
+        const float *src = hot ? f.dQ + (uint64_t)ent[sl].x * k : f.stage + (uint64_t)fold_block(ent[sl].y) * k;
 #pragma unroll
         for (int r = 0; r < KR; ++r) { st[sl][0][r] = YUE_FOLD_LD(src + el[r]); if (!hot) st[sl][1][r] = YUE_FOLD_LD(src + (uint64_t)k + el[r]); }
-        if (!hot && c > 2u) {
+        if (c > 2u) {
 #pragma unroll
             for (unsigned q = 2; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < KR; ++r) st[sl][q][r] = YUE_FOLD_LD(src + (uint64_t)(q < c ? q : 0u) * k + el[r]);
         }
+        big = big || c > 4u;
 #pragma unroll
         for (int r = 0; r < KR; ++r) x[sl][r] = YUE_FOLD_LDROW(row + el[r]);
     }
 #pragma unroll
     for (int sl = 0; sl < EPG; ++sl) {
         if ((uint32_t)sl >= nact) continue;
-        const uint32_t c = meta_class(ent[sl].y);
-        const bool hot = c >= kMetaHot;
+        const uint32_t c = fold_count(ent[sl].y);
+        const bool hot = c == 0u;
         float *row = f.Q + (uint64_t)ent[sl].x * k;
         float *dr = f.dQ + (uint64_t)ent[sl].x * k;
 #pragma unroll
@@ -485,8 +490,35 @@ __device__ __forceinline__ void fold_group(const FoldArgs &f, int lane, unsigned
             const unsigned e = 64u * r + lane;
             float acc = st[sl][0][r];
 #pragma unroll
-            for (unsigned q = 1; q < kMetaStageMax; ++q) { const float v = (!hot && q < c) ? st[sl][q][r] : 0.0f; acc = acc + v; }
-            if (e < k) { row[e] = x[sl][r] + acc; if (hot) dr[e] = 0.0f; }
+            for (unsigned q = 1; q < 4; ++q) { const float v = q < c ? st[sl][q][r] : 0.0f; acc = acc + v; }
+            st[sl][0][r] = acc;
+            if (c <= 4u && e < k) { row[e] = x[sl][r] + acc; if (hot) dr[e] = 0.0f; }
+        }
+    }
+    if (big) {                                           // wave-uniform; the rest of a large block in ticket order
+#pragma unroll
+        for (int sl = 0; sl < EPG; ++sl) {
+            if ((uint32_t)sl >= nact) continue;
+            const uint32_t c = fold_count(ent[sl].y);
+            if (c <= 4u) continue;
+            const float *src = f.stage + (uint64_t)fold_block(ent[sl].y) * k;
+            float *row = f.Q + (uint64_t)ent[sl].x * k;
+            float acc[KR];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) acc[r] = st[sl][0][r];
+            for (uint32_t q0 = 4u; q0 < c; q0 += 4u) {
+                float v[4][KR];
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) v[q][r] = YUE_FOLD_LD(src + (uint64_t)(q0 + q < c ? q0 + q : q0) * k + el[r]);
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) acc[r] = acc[r] + (q0 + q < c ? v[q][r] : 0.0f);
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; if (e < k) row[e] = x[sl][r] + acc[r]; }
         }
     }
 }
