@@ -113,6 +113,10 @@ def cpu_baseline(data, P0, Q0, j_first, k, budget_s=8.0):
 
 
 def scan_kernel_label(dev, k):
+    chunks = dev.get_option('scan_last_chunks')
+    if chunks > 0:      # two-phase scan of the last call: the first 512 items fused, then `chunks` filter + select launches
+        return ('k_topn_scan_bf16p (first 512 items) + %d x [k_scan_filter<K16=%d> (bf16 MFMA + margin filter -> survivor bits) + '
+                'k_scan_select (exact re-score of the survivors, list per wave)]' % (chunks, k // 16))
     if dev.get_option('scan_batch') == 1:
         return 'k_topn_scan_bf16<K16=%d, 1 tile per iteration, 4 waves>' % (k // 16)
     return 'k_topn_scan_bf16p<K16=%d, 2 tiles per iteration, 8 waves>' % (k // 16)
