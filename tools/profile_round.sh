@@ -32,7 +32,12 @@ secondary)
     python bench.py --workload c3wide --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/bench_c3wide.json 2> $out/bench_c3wide.err && echo c3wide ok
     python bench.py --workload fism --steps 3 --warmup 1 > $out/bench_fism.json 2> $out/bench_fism.err && echo fism ok ;;
 scan)
-    BENCH_ARGS="--steps 2 --warmup 4" tools/pmc_pass.sh ${tag}_scan_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS && BENCH_ARGS="--steps 2 --warmup 4" tools/pmc_pass.sh ${tag}_scan_gui GRBM_GUI_ACTIVE ;;
+    # counters of the scoring kernels on all 1M users of config 5: random factors (every tile scored) and the factors 25 epochs leave
+    for ep in 0 25; do
+        PROBE_DEFAULT=1 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d gpurun_out/pm/${tag}_scan_sq_$ep -- python3 tools/scan_probe.py $ep > gpurun_out/pm/${tag}_scan_sq_$ep.log 2>&1 && python tools/pmc_summary.py gpurun_out/pm/${tag}_scan_sq_$ep > gpurun_out/pm/${tag}_scan_sq_$ep.txt && rm -rf gpurun_out/pm/${tag}_scan_sq_$ep && echo "scan SQ pass ($ep epochs) done"
+        PROBE_DEFAULT=1 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pm/${tag}_scan_gui_$ep -- python3 tools/scan_probe.py $ep > gpurun_out/pm/${tag}_scan_gui_$ep.log 2>&1 && python tools/pmc_summary.py gpurun_out/pm/${tag}_scan_gui_$ep > gpurun_out/pm/${tag}_scan_gui_$ep.txt && rm -rf gpurun_out/pm/${tag}_scan_gui_$ep && echo "scan GUI pass ($ep epochs) done"
+        grep "epochs," gpurun_out/pm/${tag}_scan_gui_$ep.log
+    done ;;
 exact)
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kx -- python3 tools/exact_probe.py c3 2 > $out/kx.log 2>&1 && cp $(find $out/kx -name '*kernel_stats.csv' | head -1) $out/exact_c3_kernel_stats.csv && rm -rf $out/kx && echo exact kernel stats ok ;;
 *) echo "unknown stage $st" ;;

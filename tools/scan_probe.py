@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing probe of the scoring paths on config 5: python tools/scan_probe.py EPOCHS [users]  (EPOCHS = 0: random factors)
-prints kernel ms of yue_topn_scan for the fused kernel and the two-phase path (several chunk growth factors)."""
+prints kernel ms of yue_topn_scan for the fused kernel and the two-phase path (several chunk growth factors);
+PROBE_DEFAULT=1: only the library's default path (for counter passes)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,8 @@ for ep in range(epochs):
     dev.bpr_epoch(20260003, ep, 0, 0.02, 0.01, 0.01)
 users = np.arange(nu, dtype=np.int32)
 ref = None
-for label, opts in [('fused', {'scan_two_phase': 0}), ('two-phase x2', {'scan_two_phase': 1, 'scan_growth': 2}), ('two-phase x4', {'scan_two_phase': 1, 'scan_growth': 4}),
+configs = [('default (two-phase, growth chosen from the first chunk)', {})] if os.environ.get('PROBE_DEFAULT') else None
+for label, opts in configs or [('fused', {'scan_two_phase': 0}), ('two-phase x2', {'scan_two_phase': 1, 'scan_growth': 2}), ('two-phase x4', {'scan_two_phase': 1, 'scan_growth': 4}),
                     ('two-phase x8', {'scan_two_phase': 1, 'scan_growth': 8}), ('two-phase x16', {'scan_two_phase': 1, 'scan_growth': 16})]:
     for a, b in opts.items():
         dev.set_option(a, b)
