@@ -119,10 +119,11 @@ int yue_epoch_plan(int64_t m, int k, int64_t round_events, double events_total, 
 
 /* The default round size of yue_bpr_epoch for the uploaded factors on this device.  One resident set of waves of the
  * round kernel takes 57,344 events on MI355X at k = 128 (49,152 for the kernels that finish contended rows inside
- * the launch: option round_fold / round_meta = 0, and yue_bpr_rounds); the default is up to 3 such sets, as long as
- * a round holds at most one event per item row of this rank (job-wide average on a communicator: the call is then
- * collective) -- 172,032 on BASELINE config 3.  Results depend on the round size: pass an
- * explicit value where runs must be comparable across devices. */
+ * the launch: option round_fold / round_meta = 0, and yue_bpr_rounds); the default is up to 6 such sets, as long as
+ * a round holds at most four events per item row of this rank (job-wide average on a communicator: the call is then
+ * collective), at most 4 sets for rounds with fewer than two touches per item row -- 344,064 on BASELINE config 3,
+ * 172,032 on config 2.  Results depend on the round size (DESIGN.md section 3 tabulates the distance from the
+ * sequential loop against it): pass an explicit value where runs must be comparable across devices. */
 int yue_default_round_events(yue_ctx *ctx, int64_t *out);
 
 /* Negatives the device sampler draws for (seed, epoch): j_out[E], -1 where all attempts were rejected. */
@@ -162,16 +163,25 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
 /* Tuning / diagnostic knobs (results do not depend on them, except that round_stage changes the order of some fp32 sums):
  *   "scan_f32"  1 = always score with the exact f32-MFMA kernel instead of bf16 pre-filter + exact re-score
  *   "scan_batch" bf16 scoring kernel: 0 (default) two item tiles per loop iteration and 256 users per workgroup, 1 one tile and 128 users
- *   "round_tpw" events per wave in the training round kernel: 0 = default (16 for k <= 64, 8 for k <= 128, else 4), 2, 4, 8, 16 (k <= 64 only)
- *   "round_stage" 1 (default): item rows touched 2..4 times in a round collect their differences in staging rows,
- *               summed in ticket / event order when the row is rewritten; 2..4: that bound chosen explicitly (epoch
- *               path); 0: every contended row goes through float atomics
+ *   "round_tpw" events per wave in the training round kernel: 0 = default (8 for k <= 128 -- 16 for k <= 64 in yue_bpr_rounds --, else 4), 2, 4, 8, 16 (k <= 64 only)
+ *   "round_stage" 1 (default): item rows touched a few times in a round collect their differences in staging rows,
+ *               summed in ticket / event order when the row is rewritten -- up to 4 touches in yue_bpr_rounds; in the
+ *               epoch path up to a bound sized from the round's mean touches per item row (2x the mean at k > 64,
+ *               4x at k <= 64, between 4 and 64; read it back as "round_last_stage_max"); 2..64: that bound chosen
+ *               explicitly (epoch path); 0: every contended row goes through float atomics
  *   "round_meta" 1 (default): yue_bpr_epoch takes the touch metadata of all rounds from one pre-pass per epoch
  *               (k_round_meta), round launches without a retire phase (k_round_m) and a fold launch behind each
  *               (k_round_fold) -- item shards of up to 8.4M rows (above 454,656: touches bucketed by item range first); 0: touches counted and contended rows finished
  *               inside the round launches (k_round, the kernel of yue_bpr_rounds).  Also moves yue_default_round_events.
  *   "round_bucket" 1: the bucketed pre-pass also for small catalogues (tests)
  *   "fold_blocks" workgroups of the fold launch (default 1536)
+ *   "scan_two_phase" 1 (default): yue_topn_scan on catalogues of >= 16,384 items (k in {16,32,64,128}, N <= 64, bf16 path) scores
+ *               the first 512 items with the fused kernel and the rest in chunks through k_scan_filter + k_scan_select; 0: the
+ *               fused kernel for everything (same lists and scores)
+ *   "scan_growth" 0 (default): each chunk of the two-phase scan ends at 2x or 8x the items scanned so far, chosen from the
+ *               list-update rate of the first 512 items; 2..64: that factor
+ *   "fism_lds"   1 (default): yue_fism_rounds keeps a user's working rows in LDS when they fit (k_fism_round_lds); 0: always the
+ *               form with working rows in global memory and host-built item lists
  *   "chain_waves" exact path: workgroups (of four waves) per CU of the dataflow launch, 1..8 (0 = default: 1)
  *   "chain_split" exact path: 1 = a run is walked by a PAIR of waves (k_bpr_chain2: one keeps the memory side, the other the
  *               dependency chain margin -> sigmoid -> user row; same results bit for bit; measured no faster: default 0)
@@ -182,7 +192,8 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *   "replay_levels" 1 = yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path, kept for
  *               comparison; same results)
  * Read-only (yue_get_option): "chain_last_runs" / "chain_last_waves" (runs walked / waves launched by the last exact launch),
- *   "replay_last_levels" (dependency levels of the last levelled replay)
+ *   "replay_last_levels" (dependency levels of the last levelled replay), "scan_last_chunks" (filter + select launches of the
+ *   last two-phase scan; 0: the fused kernel ran), "round_last_stage_max" (largest staged block of the last epoch's pre-pass)
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
  *               the reference's order-dependent overwrite-scan */

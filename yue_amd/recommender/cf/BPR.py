@@ -12,7 +12,7 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
   bpr.hip=-mode epoch -round auto -seed 1
                                         throughput mode: counter-based sampler on the device,
                                         S-round semantics; -round N fixes the round size
-                                        (auto = the device's default: yue_default_round_events, 172,032 events on MI355X for BASELINE config 3).
+                                        (auto = the device's default: yue_default_round_events, 344,064 events on MI355X for BASELINE config 3).
   bpr.hip=-mode exact -seed 1           the device's counter-based sampler with the reference's EXACT sequential semantics (one dataflow
                                         launch per epoch, chain_kernels.hpp): the loop of BPR.py:42-58 on other negatives than
                                         Python's; needs no host sampling, so it also serves array-native data.
