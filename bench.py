@@ -18,7 +18,7 @@ One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the lib
 `cpu_baseline` (oracle/ timed on one host core, N=1 only) and, at N=1:
   `config.deviation_vs_sequential`  how far ONE epoch of the timed S-round semantics lands from the reference's sequential
                   loop run on the same factors and negatives (the exact device path, itself checked against the oracle);
-  `secondary.exact`  the EXACT path (recommender/cf/BPR.py:40-62 semantics, chain_kernels.hpp) on config 3 and config 2:
+  `secondary.exact`  the EXACT path (recommender/cf/BPR.py:40-62 semantics, chain_kernels.hpp) on config 3, config 2 and one rank's share of config 4:
                   triplets/s of a whole epoch, dependency depth of the stream, and the same stream through yue_bpr_replay
                   from host arrays;
   `secondary.c5`  the top-N scoring path (BASELINE config 5: all 1M users x 200K items, the factors the timed epochs left)
@@ -294,6 +294,27 @@ def secondary_exact(dev, data, P0, Q0, seed, k, no_cpu):
     data2 = synth.make_arrays(m2, n2, d2, seed=20260001)
     P2, Q2 = synth.init_factors(m2, n2, k2, 20260002)
     out['c2'] = exact_line(dev, 'C2: 100000 users x 50000 items, k=64, 50 events/user', data2, P2, Q2, seed, k2, 2, no_cpu)
+    del data2, P2, Q2
+    # one rank's share of config 4: 6 events per user -> a shallow dependency graph
+    m4, n4, d4, k4 = WORKLOADS['c4shard']
+    data4 = synth.make_arrays(m4, n4, d4, seed=20260001)
+    P4, Q4 = synth.init_factors(m4, n4, k4, 20260002)
+    prefix4 = None
+    if not no_cpu:
+        import oracle
+        S = 2000000
+        dev.set_factors(P4, Q4)
+        dev.set_interactions(data4['indptr'], data4['indices'], data4['ev_ptr'], data4['ev_i'])
+        j4 = dev.sample_negatives(seed, 0)
+        ev_u4 = np.repeat(np.arange(m4, dtype=np.int32), np.diff(data4['ev_ptr']))
+        users = int(ev_u4[S - 1]) + 1                      # the prefix only touches the first users' rows
+        Ps, Qs = P4[:users].copy(), Q4.copy()
+        oracle.Oracle().bpr_sequential(Ps, Qs, ev_u4[:S], data4['ev_i'][:S], j4[:S], LR, REG_U, REG_I)
+        Pfull = P4.copy()
+        Pfull[:users] = Ps
+        prefix4 = (S, Pfull, Qs)
+        del ev_u4, j4
+    out['c4shard'] = exact_line(dev, 'C4 shard: 10000000 users x 125000 items, k=128, 6 events/user', data4, P4, Q4, seed, k4, 2, no_cpu, prefix4)
     return out
 
 

@@ -2,12 +2,13 @@
 
   * config 3 (1M users x 200K items, k=128, 50M triplets, the device's default round size): one full
     epoch against the oracle's restatement of the same rounds (oracle/bpr_oracle.c: orc_bpr_rounds) --
-    the bench workload itself, at the real Zipf contention and the default W (172,032: metadata pre-pass,
+    the bench workload itself, at the real Zipf contention and the default W (344,064: metadata pre-pass,
     round launches without retire phase, fold launches);
   * one GPU's share of config 4 (10M users -> 5.1 GB of replicated user factors, a 125K-item shard,
     60M events) through the communicator code path (1-rank RCCL communicator: all-reduce + range apply
     on the second stream) against the same oracle (world = 1: the sharded spec IS the S-round oracle
-    with rounds cut at user blocks, tests/test_dist_cpu.py::test_one_rank_spec_equals_plain_rounds);
+    with rounds cut at user blocks, tests/test_dist_cpu.py::test_one_rank_spec_equals_plain_rounds); the same shard
+    through the EXACT path (60M triplets, 10M runs) against the oracle's sequential loop;
   * config 3 and config 2 (100K x 50K, k=64): how far one S-round epoch (the throughput semantics) lands from the
     reference's strictly sequential loop (recommender/cf/BPR.py:40-62, orc_bpr_sequential) on the same
     negatives -- the semantic deviation, with a stated bound.
@@ -93,6 +94,30 @@ def test_config4_shard_through_the_communicator_path(orc):
         dev.close()
 
 
+def test_config4_shard_exact_epoch_matches_the_sequential_oracle(orc):
+    # the reference's sequential semantics on one rank's share of config 4: 10M runs of 6 triplets, user factors beyond 2 GiB
+    m, n, d, k = 10000000, 125000, 6, 128
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    dev = _fresh_device()
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        j = dev.sample_negatives(20260003, 0)
+        dev.set_option('epoch_exact', 1)
+        t0 = time.time()
+        nll_x, _, _ = dev.bpr_epoch(20260003, 0, 0, LR, REG_U, REG_I)
+        t_dev = time.time() - t0
+        Px, Qx = dev.get_factors()
+    finally:
+        dev.close()
+    nll_s = orc.bpr_sequential(P0, Q0, ev_u, data['ev_i'], j, LR, REG_U, REG_I)       # in place on the initial arrays
+    print('C4 shard exact epoch on the device (%.0f ms incl. first-call allocations) vs the sequential oracle: bit-equal P %.5f Q %.5f, rel P %.1e Q %.1e'
+          % (1e3 * t_dev, np.mean(Px == P0), np.mean(Qx == Q0), rel_err(Px, P0), rel_err(Qx, Q0)))
+    assert rel_err(Px, P0) < 1e-6 and rel_err(Qx, Q0) < 1e-6 and abs(nll_x - nll_s) <= 1e-9 * nll_s
+
+
 def _round_semantics_vs_sequential(orc, m, n, d, k, tag):
     data = synth.make_arrays(m, n, d, seed=20260001)
     P0, Q0 = synth.init_factors(m, n, k, 20260002)
@@ -132,9 +157,9 @@ def _round_semantics_vs_sequential(orc, m, n, d, k, tag):
 
 
 def test_config3_round_semantics_vs_the_sequential_loop(orc):
-    # the bench workload itself: one epoch of the throughput semantics at the default W (172,032 events per round) against the
+    # the bench workload itself: one epoch of the throughput semantics at the default W (344,064 events per round) against the
     # reference's strictly sequential loop on identical negatives (50M triplets through the C oracle: under a minute)
-    # Bounds = 1.5 x the measured values (profiles/r03_deviation_c3.jsonl: loss +0.320 %, distance / movement 0.0897 (P), 0.0197 (Q);
+    # Bounds = 1.5 x the measured values (profiles/r03_deviation_c3.jsonl: loss +0.332 %, distance / movement 0.0902 (P), 0.0199 (Q);
     # the distance hardly depends on W -- 0.0896 / 0.0195 at W = 8,192 -- because a user's own events always share one round)
     dloss, rP, rQ = _round_semantics_vs_sequential(orc, 1000000, 200000, 50, 128, 'C3')
     assert dloss < 4.8e-3 and rP < 0.135 and rQ < 0.030

@@ -219,6 +219,26 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (tpw, stage, meta)
 
 
+def test_staged_block_size_follows_the_rounds_mean_touches_per_row():
+    # default round_stage: largest staged block = ceil(2 x mean touches per item row) at k > 64, 4 x at k <= 64, within 4..64
+    # (mean = 2 x events of the widest round / item rows; rounds are blocks of whole users: 328 users x 25 events here)
+    from yue_amd._shim import Device
+    m, n, d, W = 4000, 2500, 25, 8192
+    for k, want in ((128, 14), (64, 27), (200, 14)):
+        data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=21)
+        dev = Device(0, raise_errors=True)
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        dev.bpr_epoch(9, 0, W, 0.02, 0.01, 0.01)
+        assert dev.get_option('round_last_stage_max') == want, (k, dev.get_option('round_last_stage_max'))
+        dev.bpr_epoch(9, 1, 64, 0.02, 0.01, 0.01)             # rounds of 3 users = 75 events on 2,500 rows: the floor of 4
+        assert dev.get_option('round_last_stage_max') == 4
+        dev.set_option('round_stage', 9)
+        dev.bpr_epoch(9, 2, W, 0.02, 0.01, 0.01)
+        assert dev.get_option('round_last_stage_max') == 9
+        dev.close()
+
+
 def test_epoch_metadata_pre_pass_over_several_item_ranges(orc):
     # n above one LDS range of the pre-pass (37,888 item rows): three ranges per round, staging blocks of one round handed
     # out by several work items; a popular head (rows with hundreds of touches per round -> float atomics), rows with 2..4
