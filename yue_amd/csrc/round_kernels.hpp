@@ -27,14 +27,19 @@
 #endif
 
 #define YUE_BLOAD_NT(rs, vo, so) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rs), (vo), (so), 2))
-// item-row gathers are non-temporal (measured on C3: 32.4 against 33.0 ms/epoch -- a round reads most rows once, the
-// cache space is worth more to the staged rows, which the fold launch reads back: non-temporal STORES of those cost 1.6 ms)
+// the gathers of NEGATIVE item rows (uniform over the catalogue: no re-use) are non-temporal; positives (Zipf head: an XCD's L2
+// serves some of the repeats) are cached.  Measured on C3: both non-temporal 32.4 against 33.0 ms/epoch both cached (round 2);
+// positives cached 28.45 against 28.8 both non-temporal (round 3, two runs each on one box; C2 unchanged).  The cache space
+// is worth more to the staged rows, which the fold launch reads back: non-temporal STORES of those cost 1.6 ms.
 #if defined(YUE_EXP_LOAD_CACHED)
 #define YUE_M_LOAD_J(rs, vo, so) YUE_BLOAD(rs, vo, so)
 #define YUE_M_LOAD_I(rs, vo, so) YUE_BLOAD(rs, vo, so)
-#else
+#elif defined(YUE_EXP_LOAD_NT)
 #define YUE_M_LOAD_J(rs, vo, so) YUE_BLOAD_NT(rs, vo, so)
 #define YUE_M_LOAD_I(rs, vo, so) YUE_BLOAD_NT(rs, vo, so)
+#else
+#define YUE_M_LOAD_J(rs, vo, so) YUE_BLOAD_NT(rs, vo, so)
+#define YUE_M_LOAD_I(rs, vo, so) YUE_BLOAD(rs, vo, so)
 #endif
 
 // the fold launch reads every staged row exactly once: non-temporal (32.3 against 32.6 ms/epoch)
