@@ -193,7 +193,8 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *               comparison; same results)
  * Read-only (yue_get_option): "chain_last_runs" / "chain_last_waves" (runs walked / waves launched by the last exact launch),
  *   "replay_last_levels" (dependency levels of the last levelled replay), "scan_last_chunks" (filter + select launches of the
- *   last two-phase scan; 0: the fused kernel ran), "round_last_stage_max" (largest staged block of the last epoch's pre-pass)
+ *   last two-phase scan; 0: the fused kernel ran), "scan_last_settle" (1: most sampled users were settled against the catalogue's
+ *   tail after the first chunk, the filter ran in the variant whose workgroups stop then), "round_last_stage_max" (largest staged block of the last epoch's pre-pass)
  * Behaviour switch (off by default = the reference's behaviour):
  *   "topn_true" 1 = yue_topn_scan returns a real top-N (descending, ties: lower item id first) instead of
  *               the reference's order-dependent overwrite-scan */

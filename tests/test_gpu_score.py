@@ -273,3 +273,37 @@ def test_two_phase_scan_equals_the_fused_kernel_and_the_oracle(dev, orc, m, n, k
         assert np.array_equal(ids, ids_f) and np.array_equal(sc, sc_f) and events == events_f
         oid, osc, rc = (orc.topn_true if true_topn else orc.topn_scan)(P, Q, users, N, mp, mi)
         assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+
+
+@pytest.mark.parametrize('m,n,k,N', [(1500, 60000, 128, 20), (700, 40000, 64, 10)])
+def test_two_phase_scan_with_settled_users(dev, orc, m, n, k, N):
+    """Item norms that fall along the catalogue (what a few epochs of training leave on popularity-ordered items): most users
+    are settled against the tail after the first chunks, the filter runs in its variant whose workgroups stop then
+    (k_scan_filter<.., SETTLE>); some users get a late strong item so that not every workgroup stops at the same place."""
+    rs = np.random.RandomState(5 + k)
+    P = (rs.rand(m, k).astype(np.float32) - 0.3) / 4
+    Q = (rs.rand(n, k).astype(np.float32) - 0.3) / 4
+    Q *= (1.0 / (1.0 + np.arange(n, dtype=np.float32) / 300.0))[:, None]
+    P[3 * m // 4:] -= P[3 * m // 4:].mean(axis=1, keepdims=True)     # a quarter of the users with low scores for their norm: they settle late or never
+    late = ((3, 3000), (700 % m, 4000), (m - 1, 3500))
+    for u, it in late:
+        Q[it] = 0.5 * P[u] / np.linalg.norm(P[u])               # an item of the second chunk that must still enter user u's list
+    indptr = np.arange(m + 1, dtype=np.int64) * 4
+    indices = (rs.randint(0, n // 4, size=(m, 4)) + np.arange(4) * (n // 4)).astype(np.int32).reshape(-1)     # sorted, distinct per row
+    indices[0:4] = [0, 1, 2, 3]
+    users = np.arange(m, dtype=np.int32)
+    mp, mi = mask_rows(indptr, indices, users)
+    dev.set_factors(P, Q)
+    ids, sc = dev.topn_scan(users, N, mp, mi)
+    assert dev.get_option('scan_last_chunks') >= 2 and dev.get_option('scan_last_settle') == 1
+    done, total = dev.scan_work()
+    assert done < 0.5 * total                                   # most tiles were never scored
+    oid, osc, rc = orc.topn_scan(P, Q, users, N, mp, mi)
+    assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    assert all(it in ids[u] for u, it in late)
+    dev.set_option('scan_two_phase', 0)
+    try:
+        ids_f, sc_f = dev.topn_scan(users, N, mp, mi)
+    finally:
+        dev.set_option('scan_two_phase', 1)
+    assert np.array_equal(ids, ids_f) and np.array_equal(sc, sc_f)

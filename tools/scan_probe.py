@@ -7,7 +7,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from yue_amd import synth
+from yue_amd import _shim
 from yue_amd._shim import Device
+if os.environ.get('YUE_LIB'):
+    _shim.LIB_PATH = os.environ['YUE_LIB']
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 m, n, d, k, N = 1000000, 200000, 50, 128, 20
 nu = int(sys.argv[2]) if len(sys.argv) > 2 else m

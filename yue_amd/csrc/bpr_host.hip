@@ -734,6 +734,7 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "fism_lds") *value = c->opt_fism_lds;
     else if (key == "scan_growth") *value = c->opt_scan_growth;
     else if (key == "scan_last_chunks") *value = c->scan_chunks;
+    else if (key == "scan_last_settle") *value = c->scan_settle;
     else if (key == "topn_true") *value = c->opt_topn_true;
     else if (key == "round_stage") *value = c->opt_round_stage;
     else if (key == "round_last_stage_max") *value = c->last_stage_max;

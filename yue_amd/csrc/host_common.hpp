@@ -103,6 +103,7 @@ struct yue_ctx {
     int opt_scan_batch = 0;              // bf16 scoring kernel: 0 = two tiles per iteration, 256 users per workgroup (default); 1 = one tile, 128 users
     int opt_round_tpw = 0;               // 0: default events per wave in the round kernel
     int opt_topn_true = 0;               // 1: yue_topn_scan returns a real top-N instead of the reference's overwrite-scan
+    int scan_settle = 0;                 // the last two-phase scan used the filter variant that stops settled workgroups (read-only option scan_last_settle)
     int last_stage_max = 0;              // largest staged block of the last pre-pass (read-only option round_last_stage_max)
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 1: sized from the round's mean touches per row; 2..64: rows with up to that many touches are staged (epoch path)
     int opt_round_bucket = 0;            // 1: the bucketed pre-pass also for small catalogues (tests)

@@ -29,6 +29,7 @@ struct FilterArgs {
     int N;
     const float *thr_rows;       // [nu][N] the lists' scores so far: threshold of user t = thr_rows[t * N + N - 1]
     const float *tile_norm_max;  // max ||Q_i|| per tile of 32 items (global tile index)
+    const float *tile_norm_sufmax; // max of tile_norm_max over this and all later tiles (a workgroup whose users are all settled against it stops)
     int64_t item0, item1;        // the chunk; item0 is a multiple of 64
     int64_t iters_per_block;     // stages of 64 items one workgroup takes (blockIdx.y-th share of the chunk)
     uint32_t *masks;             // [nu][mask_stride]: word w of a user = tile item0 / 32 + w; only words with survivors are written
@@ -43,15 +44,36 @@ __global__ void __launch_bounds__(256) k_q_to_bf16(const float *Q, __bf16 *Qb, i
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += stride) Qb[t] = t < count ? (__bf16)Q[t] : (__bf16)0.0f;
 }
 
+// Which regime is the scan in?  Every `step`-th user, one wave each: is the user settled against all items from `item` on
+// (||P_u|| * max later ||Q_i|| <= the threshold its first chunk left)?  counts[0] += sampled users, counts[1] += settled ones.
+__global__ void __launch_bounds__(256) k_scan_settled_sample(const float *P, const int32_t *users, int64_t nu, int k, int N, const float *thr_rows,
+                                                             const float *tile_norm_sufmax, int64_t item, int step, unsigned *counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t upos = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * step;
+    if (upos >= nu) return;
+    const float *prow = P + (int64_t)users[upos] * k;
+    float ss = 0.0f;
+    for (int e = lane; e < k; e += 64) ss = __builtin_fmaf(prow[e], prow[e], ss);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) {
+        atomicAdd(counts, 1u);
+        if (__builtin_sqrtf(ss) * 1.0001f * tile_norm_sufmax[item / kScanTile] <= thr_rows[upos * N + N - 1]) atomicAdd(counts + 1, 1u);
+    }
+}
+
 // A wave takes UB blocks of 32 users: one item-tile fragment read from LDS feeds UB MFMAs (at UB = 1 the LDS reads of the
 // fragments take as long as the MFMAs they feed: 16 x 1 KB per wave and 64 items against 16 x 32 cycles of the matrix pipe).
-template <int K16, int WAVES, int UB>
+template <int K16, int WAVES, int UB, bool SETTLE>
 __global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int K = 16 * K16, LDB = K + kScanBfPad, NT = 64 * WAVES, ROWS = 64;
     __bf16 *btile = reinterpret_cast<__bf16 *>(lds_raw);                 // [2][64][LDB]
+    __shared__ unsigned settled_waves;                                   // waves none of whose users can take a later item
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    bool wave_settled = false;
+    if (tid == 0) settled_waves = 0u;
     int64_t upos[UB];
     bool uvalid[UB];
     bf16x8 af[UB][K16];
@@ -100,12 +122,39 @@ __global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
 #pragma unroll
     for (int b = 0; b < UB; ++b) summ[b] = 0u;
     if (it_begin >= niter) return;
+    float sm_next = SETTLE ? a.tile_norm_sufmax[(a.item0 + it_begin * ROWS) / kScanTile] : 0.0f;
     fetch(a.item0 + it_begin * ROWS);
     commit((int)(it_begin & 1));
     __syncthreads();
     for (int64_t it = it_begin; it < niter; ++it) {
         const int stage = (int)(it & 1);
         const int64_t it0 = a.item0 + it * ROWS;
+        if (SETTLE && ((it - it_begin) & 63) == 0) {
+            // every 64 stages (four summary words): can any user of this wave still take an item from here on?  (Cauchy-Schwarz
+            // against the largest norm of ALL later items -- trained factors: the catalogue's tail cannot reach the lists.)  A wave
+            // that cannot says so once in LDS; when all waves have, the rest of the workgroup's share has no survivors: zero
+            // summary words, nothing else to write or read.  No barrier: a wave that reads the count too early leaves one check
+            // later (its stages in between score nothing), the barriers of the stage loop only count waves that still run.
+            if (!wave_settled) {
+                const float sm = sm_next;
+                {   // the next check's value now: its load latency stays out of the check
+                    const int64_t itn = it + 64 < niter ? it + 64 : it;
+                    sm_next = a.tile_norm_sufmax[(a.item0 + itn * ROWS) / kScanTile];
+                }
+                bool open_ = false;
+#pragma unroll
+                for (int b = 0; b < UB; ++b) open_ = open_ || (uvalid[b] && !(pn[b] * sm <= thr[b]));
+                wave_settled = __ballot(open_) == 0ull;
+                if (wave_settled && lane == 0) atomicAdd(&settled_waves, 1u);
+            }
+            if (wave_settled && __hip_atomic_load(&settled_waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)WAVES) {
+#pragma unroll
+                for (int b = 0; b < UB; ++b)
+                    if (h == 0 && uvalid[b])
+                        for (int64_t g = it >> 4; g <= (niter - 1) >> 4; ++g) a.summary[upos[b] * a.sum_stride + g] = 0u;
+                break;
+            }
+        }
         const __bf16 *tbb = btile + stage * ROWS * LDB;
         if (it + 1 < niter) fetch(it0 + ROWS);
         const int64_t tl = it0 / kScanTile;
