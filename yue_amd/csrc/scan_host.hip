@@ -81,7 +81,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
         unsigned *settle_counts = reinterpret_cast<unsigned *>(c->s_flags.p + 2);
         constexpr int kSettleStep = 16;
         const int64_t settle_item = std::min<int64_t>(c->n - 1, 8 * kChunk0);
-        hipLaunchKernelGGL(yue::k_scan_settled_sample, dim3((unsigned)(((nu + kSettleStep - 1) / kSettleStep + 3) / 4)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(yue::k_scan_settled_sample, dim3((unsigned)(((nu + kSettleStep - 1) / kSettleStep + 63) / 64)), dim3(256), 0, c->stream,
                            c->P.p, c->s_users.p, nu, c->k, N, c->s_scores.p, c->s_norms.p + ntile, settle_item, kSettleStep, settle_counts);
         unsigned settle_host[2] = {0u, 0u};
         HIPCHK(hipMemcpyAsync(settle_host, settle_counts, sizeof settle_host, hipMemcpyDeviceToHost, c->stream));

@@ -44,22 +44,27 @@ __global__ void __launch_bounds__(256) k_q_to_bf16(const float *Q, __bf16 *Qb, i
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += stride) Qb[t] = t < count ? (__bf16)Q[t] : (__bf16)0.0f;
 }
 
-// Which regime is the scan in?  Every `step`-th user, one wave each: is the user settled against all items from `item` on
-// (||P_u|| * max later ||Q_i|| <= the threshold its first chunk left)?  counts[0] += sampled users, counts[1] += settled ones.
+// Which regime is the scan in?  Every `step`-th user, a wave per 16 of them: is the user settled against all items from `item`
+// on (||P_u|| * max later ||Q_i|| <= the threshold its first chunk left)?  counts[0] += sampled users, counts[1] += settled ones
+// (one pair of atomics per wave: tens of thousands of atomics on one word would take longer than the scan's first chunk).
 __global__ void __launch_bounds__(256) k_scan_settled_sample(const float *P, const int32_t *users, int64_t nu, int k, int N, const float *thr_rows,
                                                              const float *tile_norm_sufmax, int64_t item, int step, unsigned *counts) {
     const int lane = threadIdx.x & 63;
-    const int64_t upos = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * step;
-    if (upos >= nu) return;
-    const float *prow = P + (int64_t)users[upos] * k;
-    float ss = 0.0f;
-    for (int e = lane; e < k; e += 64) ss = __builtin_fmaf(prow[e], prow[e], ss);
+    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const float sm = tile_norm_sufmax[item / kScanTile];
+    unsigned sampled = 0u, settled = 0u;
+    for (int q = 0; q < 16; ++q) {
+        const int64_t upos = (first + q) * step;
+        if (upos >= nu) break;
+        const float *prow = P + (int64_t)users[upos] * k;
+        float ss = 0.0f;
+        for (int e = lane; e < k; e += 64) ss = __builtin_fmaf(prow[e], prow[e], ss);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) {
-        atomicAdd(counts, 1u);
-        if (__builtin_sqrtf(ss) * 1.0001f * tile_norm_sufmax[item / kScanTile] <= thr_rows[upos * N + N - 1]) atomicAdd(counts + 1, 1u);
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        sampled += 1u;
+        settled += __builtin_sqrtf(ss) * 1.0001f * sm <= thr_rows[upos * N + N - 1] ? 1u : 0u;
     }
+    if (lane == 0 && sampled) { atomicAdd(counts, sampled); atomicAdd(counts + 1, settled); }
 }
 
 // A wave takes UB blocks of 32 users: one item-tile fragment read from LDS feeds UB MFMAs (at UB = 1 the LDS reads of the
