@@ -46,6 +46,8 @@ def main():
     lib = dev._lib
     lib.yue_seam_init.restype = C.c_int
     assert lib.yue_seam_init(dev._ctx, C.c_int(cp.rank), C.c_int(cp.world), cb, None) == 0
+    if W == 0:
+        W = dev.default_round_events()                             # collective (through the seam): the same value on every rank
     nll = 0.0
     for epoch in range(epochs):
         nll, sp, sq = dev.bpr_epoch(31, epoch, W, 0.05, 0.01, 0.01)
@@ -53,7 +55,7 @@ def main():
     tot = dev.allreduce_f64([nll])[0]
     P, Q = dev.get_factors()
     np.savez(os.path.join(out_dir, 'seam_rank%d.npz' % cp.rank), P=P, Q=Q, nll=nll, nll_total=tot, f32_calls=calls['f32'], elements=calls['elements'],
-             collectives=stats['collectives'], allreduce_bytes=stats['allreduce_bytes'], nranks=stats['nranks'])
+             collectives=stats['collectives'], allreduce_bytes=stats['allreduce_bytes'], nranks=stats['nranks'], round_events=W)
     cp.barrier()
     dev.close()
     cp.close()

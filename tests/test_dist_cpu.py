@@ -69,11 +69,11 @@ def test_two_rank_sharded_epoch_over_the_tcp_control_plane(tmp_path, orc, throug
     assert np.array_equal(Qs[0], r0['Q']) and np.array_equal(Qs[1], r1['Q'])
 
 
-def epoch_spec_blocks(orc, store, rank, data, P, Q, seed, epoch, round_events, lr, regU, regI, events_total):
+def epoch_spec_blocks(orc, store, rank, data, P, Q, seed, epoch, round_events, lr, regU, regI, events_total, world=2):
     """epoch_spec with the all-reduce replaced by recording this rank's block differences; valid
     because a block's users are not read again within the epoch (users never straddle blocks)."""
     from yue_amd.dist import user_block_width
-    ub = user_block_width(round_events, events_total, P.shape[0], 2)
+    ub = user_block_width(round_events, events_total, P.shape[0], world)
     pos = [0]
 
     def record(block):
@@ -81,7 +81,7 @@ def epoch_spec_blocks(orc, store, rank, data, P, Q, seed, epoch, round_events, l
         store.append((u0, u0 + len(block), block.copy()))
         pos[0] += ub
         block[:] = 0                      # leave P untouched in this pass
-    epoch_spec(orc, record, 2, rank, data, P, Q, seed, epoch, round_events, lr, regU, regI, events_total)
+    epoch_spec(orc, record, world, rank, data, P, Q, seed, epoch, round_events, lr, regU, regI, events_total)
 
 
 def test_one_rank_spec_equals_plain_rounds(orc):

@@ -33,23 +33,35 @@ def test_communicator_epoch_matches_sharded_spec(orc):
     dev.close()
 
 
-def _two_shard_reference(orc, m, n, d, k, W, epochs):
-    """Single-process emulation of the two shards with oracle arithmetic (as tests/test_dist_cpu.py does)."""
+def _shard_reference(orc, m, n, d, k, W, epochs, nranks=2):
+    """Single-process emulation of the item shards with oracle arithmetic (as tests/test_dist_cpu.py does)."""
     from test_dist_cpu import epoch_spec_blocks
-    shards = [shard_problem(r, m, n, d, k) for r in range(2)]
+    shards = [shard_problem(r, m, n, d, k) for r in range(nranks)]
     P = shards[0][1].copy()
     Qs = [sh[2].copy() for sh in shards]
     etot = float(sum(sh[0]['ev_ptr'][-1] for sh in shards))
     for epoch in range(epochs):
-        blocks = [[], []]
-        for r in range(2):
-            epoch_spec_blocks(orc, blocks[r], r, shards[r][0], P.copy(), Qs[r], 31, epoch, W, 0.05, 0.01, 0.01, etot)
-        for (u0, u1, b0), (_, _, b1) in zip(blocks[0], blocks[1]):
-            P[u0:u1] += b0 + b1
+        blocks = [[] for _ in range(nranks)]
+        for r in range(nranks):
+            epoch_spec_blocks(orc, blocks[r], r, shards[r][0], P.copy(), Qs[r], 31, epoch, W, 0.05, 0.01, 0.01, etot, nranks)
+        for per_rank in zip(*blocks):
+            u0, u1 = per_rank[0][0], per_rank[0][1]
+            total = per_rank[0][2].copy()
+            for blk in per_rank[1:]:
+                total += blk[2]                                   # rank order: the order the host-staged sum adds in
+            P[u0:u1] += total
     return P, Qs, etot
 
 
+def _two_shard_reference(orc, m, n, d, k, W, epochs):
+    return _shard_reference(orc, m, n, d, k, W, epochs, 2)
+
+
 def _spawn_two_ranks(tmp_path, script, args, local_ranks):
+    _spawn_ranks(tmp_path, script, args, local_ranks)
+
+
+def _spawn_ranks(tmp_path, script, args, local_ranks):
     import os
     import socket
     import subprocess
@@ -60,8 +72,9 @@ def _spawn_two_ranks(tmp_path, script, args, local_ranks):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(local_ranks[r]), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    world = len(local_ranks)
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(local_ranks[r]), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'helpers', script), str(tmp_path)] + [str(x) for x in args],
                                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
@@ -92,6 +105,33 @@ def test_two_rank_epoch_on_one_gpu_through_the_test_seam(tmp_path, orc):
     for r in (r0, r1):
         assert int(r['collectives']) == len(plan['groups']) and int(r['nranks']) == 2
         assert float(r['allreduce_bytes']) == 4.0 * m * k and int(r['elements']) == epochs * m * k
+
+
+def test_four_rank_epoch_on_one_gpu_through_the_test_seam(tmp_path, orc):
+    """Four processes on device 0 (item shards 0..3), the round size left to the library (yue_default_round_events is a
+    collective on a communicator: all ranks must arrive at the same value), k = 64, three epochs."""
+    import os
+    from yue_amd.dist import epoch_block_plan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, 'yue_amd', 'csrc', 'libyue_hip_seam.so')):
+        pytest.fail('yue_amd/csrc/libyue_hip_seam.so missing: run __graft_entry__.build() (make -C yue_amd/csrc test-seam)')
+    m, n, d, k, epochs, nranks = 60000, 3000, 5, 64, 3, 4
+    _spawn_ranks(tmp_path, 'seam_rank_main.py', (m, n, d, k, 0, epochs), (0,) * nranks)
+    rs = [np.load(tmp_path / ('seam_rank%d.npz' % r)) for r in range(nranks)]
+    W = int(rs[0]['round_events'])
+    assert W > 0 and all(int(r['round_events']) == W for r in rs)
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]['P'], r['P'])                 # replicated user factors stay bit-identical
+        assert r['nll_total'] == rs[0]['nll_total']
+    assert abs(rs[0]['nll_total'] - sum(float(r['nll']) for r in rs)) <= 1e-9 * abs(rs[0]['nll_total'])
+    P, Qs, etot = _shard_reference(orc, m, n, d, k, W, epochs, nranks)
+    assert rel_err(rs[0]['P'], P) < 1e-5
+    for r in range(nranks):
+        assert rel_err(rs[r]['Q'], Qs[r]) < 1e-5
+    plan = epoch_block_plan(m, k, W, etot, nranks)
+    for r in rs:
+        assert int(r['collectives']) == len(plan['groups']) and int(r['nranks']) == nranks
+        assert float(r['allreduce_bytes']) == 4.0 * m * k
 
 
 def _device_count():
