@@ -5,7 +5,9 @@ from yue_amd._shim import Device
 from yue_amd.dist import epoch_round_ptr
 from util import rel_err
 orc = oracle.Oracle()
-for case in range(10):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 10)
+worst = 0.0
+for case in range(lo, hi):
     rs = np.random.RandomState(1000 + case)
     m = int(rs.randint(1, 1500)); n = int(rs.randint(2, 4000)); k = int(rs.choice([3, 7, 16, 33, 64, 100, 128, 200]))
     W = int(rs.choice([1, 5, 37, 256, 1000, 4096, 100000]))
@@ -28,6 +30,8 @@ for case in range(10):
     for meta in (1, 0):
         dev = Device(0, raise_errors=True)
         dev.set_option('round_meta', meta)
+        stage = int(rs.choice([1, 1, 0, 2, 5, 16, 64]))
+        dev.set_option('round_stage', stage)
         dev.set_factors(P0, Q0)
         dev.set_interactions(indptr, indices, ev_ptr, ev_i)
         Po, Qo = P0.copy(), Q0.copy()
@@ -39,4 +43,8 @@ for case in range(10):
             P, Q = dev.get_factors()
             out.append((rel_err(P, Po), rel_err(Q, Qo), abs(nll - nll_o) / max(abs(nll_o), 1e-30)))
         dev.close()
-        print('case %d m %d n %d k %d W %d E %d hottest %d rounds %d meta %d:' % (case, m, n, k, W, len(ev_i), top, len(rp) - 1, meta), ' '.join('P %.1e Q %.1e nll %.1e' % o for o in out))
+        bad = max(max(o[0], o[1]) for o in out) >= 1e-5 or max(o[2] for o in out) > 1e-9
+        worst = max(worst, max(max(o[0], o[1]) for o in out))
+        if bad or hi - lo <= 10:
+            print('%scase %d m %d n %d k %d W %d E %d hottest %d rounds %d meta %d stage %d:' % ('FAIL ' if bad else '', case, m, n, k, W, len(ev_i), top, len(rp) - 1, meta, stage), ' '.join('P %.1e Q %.1e nll %.1e' % o for o in out), flush=True)
+print('cases %d..%d done, worst rel err %.2e' % (lo, hi, worst))
