@@ -49,6 +49,8 @@ WORKLOADS = {
     'tiny': (20000, 5000, 20, 128),
     # a catalogue beyond the plain pre-pass (454,656 item rows): C3's users and events on 1M items (bucketed pre-pass)
     'c3wide': (1000000, 1000000, 50, 128),
+    # an item matrix beyond 2 GiB on one GPU (2.36 GB: 64-bit row addressing in the update launch, 141 item ranges in the pre-pass)
+    'c3big': (1000000, 4600000, 50, 128),
     # one GPU's share of BASELINE config 4 (10M users x 1M items over 8 GPUs): replicated 5.1 GB of user factors,
     # a 125K-item shard, 60M of the 500M events; run with --force-comm to take the all-reduce path on one rank
     'c4shard': (10000000, 125000, 6, 128),

@@ -54,7 +54,9 @@ int yue_ctx_create(int device, yue_ctx **out);
 int yue_ctx_destroy(yue_ctx *ctx);
 int yue_sync(yue_ctx *ctx);
 
-/* Factor matrices, fp32 row-major.  k <= 256. */
+/* Factor matrices, fp32 row-major.  k <= 256, m and n below 2^31 rows, any size in bytes: item matrices of 2 GiB and more per GPU
+ * are taken by yue_bpr_epoch's default path and by the scoring calls; yue_bpr_rounds, yue_bpr_replay, the option epoch_exact and
+ * round_meta = 0 refuse them (their kernels address item rows with 31-bit byte offsets). */
 int yue_set_factors(yue_ctx *ctx, const float *P, int64_t m, const float *Q, int64_t n, int k);
 int yue_get_factors(yue_ctx *ctx, float *P, float *Q);
 

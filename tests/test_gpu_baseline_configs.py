@@ -174,3 +174,31 @@ def test_config2_round_semantics_vs_the_sequential_loop(orc):
     # distance / movement 0.0576 (P), 0.0375 (Q))
     dloss, rP, rQ = _round_semantics_vs_sequential(orc, 100000, 50000, 50, 64, 'C2')
     assert dloss < 7.0e-3 and rP < 0.087 and rQ < 0.057
+
+
+def test_item_matrix_beyond_two_gib(orc):
+    """An item matrix of 2.4 GB on one GPU (4.6M items x k = 128; 31-bit byte offsets end at 2 GiB): yue_bpr_epoch's default path
+    addresses item and staging rows through 64-bit pointers (k_round_m<.., BIGQ>, bucketed pre-pass over 141 item ranges) and
+    must match the oracle's rounds; explicit rounds and the exact path refuse such a matrix instead of wrapping around."""
+    from yue_amd._shim import YueHipError
+    m, n, d, k = 40000, 4600000, 50, 128
+    data = synth.make_arrays(m, n, d, seed=20260001)
+    P0, Q0 = synth.init_factors(m, n, k, 20260002)
+    assert Q0.nbytes > (1 << 31)
+    ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+    dev = _fresh_device()
+    try:
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        with pytest.raises(YueHipError):
+            dev.bpr_rounds(ev_u[:64], data['ev_i'][:64], np.zeros(64, np.int32) + 7, np.array([0, 64], np.int64), LR, REG_U, REG_I)
+        dev.set_option('epoch_exact', 1)
+        with pytest.raises(YueHipError):
+            dev.bpr_epoch(20260003, 0, 0, LR, REG_U, REG_I)
+        dev.set_option('epoch_exact', 0)
+        P, Q = dev.get_factors()
+        assert np.array_equal(Q[-1000:], Q0[-1000:]) and np.array_equal(P, P0)        # the refused calls changed nothing
+        del P, Q
+        _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'item matrix of 2.4 GB')
+    finally:
+        dev.close()

@@ -239,6 +239,14 @@ int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e
     const yue::TrainArgs &a = a_in;
 #endif
     const uint32_t *mi = c->meta_i.p, *mj = c->meta_j.p;
+    if (c->bigq) {              // (the default events-per-wave instances only)
+        switch (kr_of(c->k) * 16 + tpw) {
+            case 1 * 16 + 8: hipLaunchKernelGGL((yue::k_round_m<1, 8, true>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); break;
+            case 2 * 16 + 8: hipLaunchKernelGGL((yue::k_round_m<2, 8, true>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); break;
+            case 4 * 16 + 4: hipLaunchKernelGGL((yue::k_round_m<4, 4, true>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); break;
+            default: return fail(YUE_ERR_ARG, "item matrices of 2 GiB and more: only the default events-per-wave setting (round_tpw = 0)");
+        }
+    } else
 #define YUE_RM(KR_, TPW_) hipLaunchKernelGGL((yue::k_round_m<KR_, TPW_>), grid, block, 0, c->stream, a, ra, a.ev_u, a.ev_i, a.ev_j, mi, mj); break;
     switch (kr_of(c->k) * 16 + tpw) {
         case 1 * 16 + 8: YUE_RM(1, 8)
@@ -275,7 +283,12 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
     for (int64_t r = 0; r < R; ++r) widest = std::max(widest, bounds[(size_t)r + 1] - bounds[(size_t)r]);
     // the metadata word keeps a staging row index or a row's touch count in 25 bits: rounds of 2^24 events and more stay on k_round
     if (widest >= (1ll << 24)) meta = false;
-    c->staged = c->opt_round_stage && widest > 0 && (c->n + 2 * widest) * (int64_t)c->k * 4 < (1ll << 31);
+    const bool fits31 = (c->n + 2 * widest) * (int64_t)c->k * 4 < (1ll << 31);     // item rows + staging rows within 31-bit byte offsets
+    // beyond that the update launch of the epoch path addresses rows through 64-bit pointers (k_round_m<.., BIGQ>); k_round cannot
+    c->bigq = meta && !fits31;
+    if (!meta && (int64_t)c->n * c->k * 4 >= (1ll << 31))
+        return fail(YUE_ERR_ARG, "item matrices of 2 GiB and more per GPU are supported by yue_bpr_epoch's default path only (not by explicit rounds / round_meta = 0 / rounds of 2^24 events and more)");
+    c->staged = c->opt_round_stage && widest > 0 && (fits31 || c->bigq);
     if (c->staged) {
         const size_t need = (size_t)(c->n + 2 * widest) * (size_t)c->k;
         if (c->Q.n < need) {                                // grow the item allocation, keep the rows

@@ -86,7 +86,8 @@ int yue_set_factors(yue_ctx *c, const float *P, int64_t m, const float *Q, int64
     if (!c || !P || !Q) return fail(YUE_ERR_ARG, "yue_set_factors: null argument");
     if (m <= 0 || n <= 0 || k <= 0 || k > 256) return fail(YUE_ERR_ARG, "yue_set_factors: need m,n > 0 and 1 <= k <= 256");
     if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: ids must fit int32");
-    if (n * (int64_t)k * 4 >= (1ll << 31)) return fail(YUE_ERR_ARG, "yue_set_factors: the item matrix of one GPU must stay below 2 GiB (n*k*4 < 2^31): shard the items");
+    // (item matrices of 2 GiB and more: yue_bpr_epoch's default path and the scoring calls take them -- 64-bit row addressing,
+    // round_kernels.hpp: BIGQ --; explicit rounds, the exact path and round_meta = 0 say so and refuse)
     HIPCHK(hipSetDevice(c->device));
     if (c->have_inter && (m != c->m || n != c->n || k != c->k)) c->have_inter = false;   // new shape (k enters the offset bounds checked by yue_set_interactions): upload the interactions again
     if (k != c->k) c->opt_round_tpw = 0;                   // the events-per-wave option was validated against the old k

@@ -66,6 +66,7 @@ struct yue_ctx {
     // staged item rows (2 per event of the widest round) live behind the n item rows in the Q allocation,
     // so that "new row in place" and "new row to my staging row" are the same store with another offset
     bool staged = false;                         // the running call uses the staging rows
+    bool bigq = false;                           // ... and addresses item / staging rows through 64-bit pointers (2 GiB and more)
     // epoch path: touch metadata of all rounds from one pre-pass (round_kernels.hpp)
     DevBuf<uint32_t> meta_i, meta_j;
     DevBuf<unsigned long long> round_rows;

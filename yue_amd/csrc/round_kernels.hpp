@@ -292,7 +292,9 @@ struct RoundMArgs {
 // stores: the round's contended rows are rewritten by k_round_fold.
 // At most 96 SGPRs: a CU then holds 7 workgroups of this kernel (floor(800 / (96 + 16)); with the 106 the compiler would
 // take it is 6, whatever the register-file arithmetic says -- DESIGN.md section 5); the excess lives in VGPR lanes.
-template <int KR, int TPW>
+// BIGQ: item matrices (+ staging rows) of 2 GiB and more -- the item rows, the staging rows and dQ are addressed through 64-bit
+// row pointers (scalar base + lane offset; lanes beyond k masked by hand) instead of one buffer descriptor with 32-bit row offsets.
+template <int KR, int TPW, bool BIGQ = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_round_m(TrainArgs a, RoundMArgs ra, const int32_t *__restrict__ evu,
                                                  const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                  const uint32_t *__restrict__ mti, const uint32_t *__restrict__ mtj) {
@@ -351,6 +353,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
     unsigned oi[TPW], oj[TPW], ou[TPW], ru_[TPW];
     bool ok[TPW];
     float qi[TPW][KR], qj[TPW][KR], p[TPW][KR];
+    unsigned el[KR];                                     // BIGQ: the lane's element of a row (clamped), and whether it exists
+    bool ev[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; ev[r] = e < k; el[r] = ev[r] ? e : 0u; }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         ru_[t] = (unsigned)hu[t];
@@ -358,8 +364,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
         ok[t] = tj >= 0;                                 // no event / sampler gave up: nothing is written
         oi[t] = (unsigned)hi_[t] * row_bytes; oj[t] = (ok[t] ? (unsigned)tj : 0u) * row_bytes;
         ou[t] = (base + t < ra.e_end ? ru_[t] - u0 : 0u) * row_bytes;
+        if (BIGQ) {
+            const float *rowi = a.Q + (uint64_t)(unsigned)hi_[t] * k, *rowj = a.Q + (uint64_t)(ok[t] ? (unsigned)tj : 0u) * k;
 #pragma unroll
-        for (int r = 0; r < KR; ++r) { qi[t][r] = YUE_M_LOAD_I(rsQ, vo[r], oi[t]); qj[t][r] = YUE_M_LOAD_J(rsQ, vo[r], oj[t]); }
+            for (int r = 0; r < KR; ++r) { qi[t][r] = ev[r] ? rowi[el[r]] : 0.0f; qj[t][r] = ev[r] ? __builtin_nontemporal_load(rowj + el[r]) : 0.0f; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { qi[t][r] = YUE_M_LOAD_I(rsQ, vo[r], oi[t]); qj[t][r] = YUE_M_LOAD_J(rsQ, vo[r], oj[t]); }
+        }
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
@@ -406,6 +418,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
             for (int r = 0; r < KR; ++r) { o[r] = bpr_elem(p[t][r], qi[t][r], qj[t][r], c, a.ru, a.ri); dp[r] += o[r].p2 - p[t][r]; }
             // the new row in place, or (new - old) to the staging row: one store, value and offset selected; a hot row's
             // difference goes into dQ with float atomics (one wave-uniform branch per touch)
+            if (BIGQ) {
+                const uint64_t ri_ = (uint64_t)(unsigned)hi_[t] * k, rj_ = (uint64_t)(unsigned)hj[t] * k;
+                float *di = hot_i ? a.dQ + ri_ : uniq_i ? a.Q + ri_ : a.stage + (uint64_t)meta_slot(hmi[t]) * k;
+                float *dj = hot_j ? a.dQ + rj_ : uniq_j ? a.Q + rj_ : a.stage + (uint64_t)meta_slot(hmj[t]) * k;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    if (ev[r]) {
+                        if (hot_i) unsafeAtomicAdd(di + el[r], o[r].qi2 - qi[t][r]); else di[el[r]] = uniq_i ? o[r].qi2 : o[r].qi2 - qi[t][r];
+                        if (hot_j) unsafeAtomicAdd(dj + el[r], o[r].qj2 - qj[t][r]); else dj[el[r]] = uniq_j ? o[r].qj2 : o[r].qj2 - qj[t][r];
+                    }
+                }
+            } else {
             if (!hot_i) {
 #pragma unroll
                 for (int r = 0; r < KR; ++r) YUE_BSTORE(uniq_i ? o[r].qi2 : o[r].qi2 - qi[t][r], rsQ, vo[r], wi);
@@ -419,6 +443,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
             } else {
 #pragma unroll
                 for (int r = 0; r < KR; ++r) YUE_M_HOT(o[r].qj2 - qj[t][r], rsdQ, vo[r], oj[t]);
+            }
             }
         }
         // end of a run of equal users (or of the batch): flush the summed P[u] differences
