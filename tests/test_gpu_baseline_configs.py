@@ -200,5 +200,14 @@ def test_item_matrix_beyond_two_gib(orc):
         assert np.array_equal(Q[-1000:], Q0[-1000:]) and np.array_equal(P, P0)        # the refused calls changed nothing
         del P, Q
         _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'item matrix of 2.4 GB')
+        # the scoring path over the same matrix (P0, Q0 now hold the oracle's state after the epoch: within 1e-5 of the device's;
+        # the lists are compared on the device's own factors)
+        P, Q = dev.get_factors()
+        users = np.array([0, 1, 17, 3999, 20000, m - 1], np.int32)
+        ids, sc = dev.topn_scan(users, 20)
+        from util import mask_rows
+        mp, mi = mask_rows(data['indptr'], data['indices'], users)
+        oid, osc, rc = orc.topn_scan(P, Q, users, 20, mp, mi)
+        assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
     finally:
         dev.close()
