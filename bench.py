@@ -40,6 +40,11 @@ from yue_amd import _shim          # noqa: E402
 from yue_amd._shim import Device   # noqa: E402
 if os.environ.get('YUE_LIB'):         # tuning experiments: another build of the library
     _shim.LIB_PATH = os.environ['YUE_LIB']
+# Rehearsal of the N > 1 flow on ONE GPU (tests/test_gpu_multi.py): every rank on device 0, the collective behind the test build's
+# host-staged seam (libyue_hip_seam.so) instead of RCCL.  Exercises this file's multi-rank logic, not the interconnect: never a result.
+SEAM_REHEARSAL = bool(os.environ.get('YUE_BENCH_SEAM'))
+if SEAM_REHEARSAL:
+    _shim.LIB_PATH = os.path.join(ROOT, 'yue_amd', 'csrc', 'libyue_hip_seam.so')
 from yue_amd.dist import ControlPlane, attach_device   # noqa: E402
 
 WORKLOADS = {
@@ -122,6 +127,29 @@ def scan_kernel_label(dev, k):
     if dev.get_option('scan_batch') == 1:
         return 'k_topn_scan_bf16<K16=%d, 1 tile per iteration, 4 waves>' % (k // 16)
     return 'k_topn_scan_bf16p<K16=%d, 2 tiles per iteration, 8 waves>' % (k // 16)
+
+
+_SEAM_KEEP = []
+
+
+def seam_attach(dev, cp):
+    """SEAM_REHEARSAL: the library's collective = a float sum over the control plane, staged through the host."""
+    import ctypes as C
+    fn_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+
+    def reduce(host, count, dtype, user):
+        try:
+            arr = np.ctypeslib.as_array(((C.c_double if dtype else C.c_float) * count).from_address(host))
+            cp.allreduce_sum(arr)
+            return 0
+        except Exception as exc:                                   # never let an exception cross the C boundary
+            print('seam reduce failed:', exc, file=sys.stderr)
+            return 1
+    cb = fn_t(reduce)
+    _SEAM_KEEP.append(cb)
+    dev._lib.yue_seam_init.restype = C.c_int
+    if dev._lib.yue_seam_init(dev._ctx, C.c_int(cp.rank), C.c_int(cp.world), cb, None) != 0:
+        sys.exit('yue_seam_init failed')
 
 
 def round_kernel_label(dev, k):
@@ -475,10 +503,13 @@ def main():
         Q0 = synth.init_factors(1, n, k, 20260002 + rank)[1]
     E = int(data['ev_ptr'][-1])
 
-    dev = Device(local_rank, raise_errors=True)
+    dev = Device(0 if SEAM_REHEARSAL else local_rank, raise_errors=True)
     dev.set_factors(P0, Q0)
     dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
-    attach_device(dev, cp)
+    if SEAM_REHEARSAL and world > 1:
+        seam_attach(dev, cp)
+    else:
+        attach_device(dev, cp)
     if args.tpw:
         dev.set_option('round_tpw', args.tpw)
     for kv in args.opt:
@@ -529,7 +560,8 @@ def main():
         out = {
             'metric': 'BPR triplet-updates/sec at k=%d' % k, 'value': value, 'unit': 'triplets/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic' if not SEAM_REHEARSAL else 'synthetic -- REHEARSAL on one GPU through the test seam: not a measurement',
             'config': {'workload': '%s: BPR k=%d, %d users x %d items per GPU, %d events/user (%d triplets per epoch per GPU), '
                                    'counter-based sampler (one pass per epoch, inside the timed step), S-round W=%d events (the device default unless --round-events is given), lr=%g regU=regI=%g'
                                    % (args.workload.upper(), k, m, n, d, E, args.round_events, LR, REG_U),

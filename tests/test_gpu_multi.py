@@ -134,6 +134,38 @@ def test_four_rank_epoch_on_one_gpu_through_the_test_seam(tmp_path, orc):
         assert float(r['allreduce_bytes']) == 4.0 * m * k
 
 
+def test_bench_multi_rank_flow_rehearsed_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU: both ranks
+    on device 0, the collective through the test seam (YUE_BENCH_SEAM).  Checks this file's multi-rank flow -- rank / world from the
+    launcher's environment, the control plane's barriers and max, the default workload for N > 1, the `comm` object, ONE JSON line
+    from rank 0 -- not the interconnect."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, 'yue_amd', 'csrc', 'libyue_hip_seam.so')):
+        pytest.fail('yue_amd/csrc/libyue_hip_seam.so missing: run __graft_entry__.build() (make -C yue_amd/csrc test-seam)')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'tiny']
+    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, YUE_BENCH_SEAM='1', OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0'),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert 'REHEARSAL' in out['data'] and 'cpu_baseline' not in out
+    assert out['comm']['collectives_per_epoch'] >= 1 and out['comm']['nranks_rccl'] == 2
+    assert out['comm']['allreduce_bytes_per_epoch_per_rank'] == 4.0 * 20000 * 128
+    assert out['roofline']['frac'] > 0 and out['config']['parallelism'].startswith('items sharded x2')
+
+
 def _device_count():
     import ctypes
     try:
