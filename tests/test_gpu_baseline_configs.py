@@ -176,12 +176,13 @@ def test_config2_round_semantics_vs_the_sequential_loop(orc):
     assert dloss < 7.0e-3 and rP < 0.087 and rQ < 0.057
 
 
-def test_item_matrix_beyond_two_gib(orc):
-    """An item matrix of 2.4 GB on one GPU (4.6M items x k = 128; 31-bit byte offsets end at 2 GiB): yue_bpr_epoch's default path
+@pytest.mark.parametrize('n,k', [(4600000, 128), (2800000, 200)])
+def test_item_matrix_beyond_two_gib(orc, n, k):
+    """An item matrix of 2.4 GB (2.2 GB) on one GPU (4.6M items x k = 128, 2.8M x 200; 31-bit byte offsets end at 2 GiB): yue_bpr_epoch's default path
     addresses item and staging rows through 64-bit pointers (k_round_m<.., BIGQ>, bucketed pre-pass over 141 item ranges) and
     must match the oracle's rounds; explicit rounds and the exact path refuse such a matrix instead of wrapping around."""
     from yue_amd._shim import YueHipError
-    m, n, d, k = 40000, 4600000, 50, 128
+    m, d = 40000, 50                                       # (k = 200: the four-registers-per-row instance, f32-MFMA scoring)
     data = synth.make_arrays(m, n, d, seed=20260001)
     P0, Q0 = synth.init_factors(m, n, k, 20260002)
     assert Q0.nbytes > (1 << 31)
@@ -199,7 +200,7 @@ def test_item_matrix_beyond_two_gib(orc):
         P, Q = dev.get_factors()
         assert np.array_equal(Q[-1000:], Q0[-1000:]) and np.array_equal(P, P0)        # the refused calls changed nothing
         del P, Q
-        _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'item matrix of 2.4 GB')
+        _epoch_vs_oracle(orc, dev, data, P0, Q0, 20260003, 0, 'item matrix of %.1f GB, k = %d' % (Q0.nbytes / 1e9, k))
         # the scoring path over the same matrix (P0, Q0 now hold the oracle's state after the epoch: within 1e-5 of the device's;
         # the lists are compared on the device's own factors)
         P, Q = dev.get_factors()
