@@ -536,14 +536,15 @@ __device__ __forceinline__ void fold_group(const FoldArgs &f, int lane, unsigned
             float acc[KR];
 #pragma unroll
             for (int r = 0; r < KR; ++r) acc[r] = st[sl][0][r];
-            for (uint32_t q0 = 4u; q0 < c; q0 += 4u) {
-                float v[4][KR];
+            constexpr unsigned STEP = KR == 1 ? 8u : 4u;      // rows in flight per step (k <= 64: blocks are long, rows short)
+            for (uint32_t q0 = 4u; q0 < c; q0 += STEP) {
+                float v[STEP][KR];
 #pragma unroll
-                for (unsigned q = 0; q < 4; ++q)
+                for (unsigned q = 0; q < STEP; ++q)
 #pragma unroll
                     for (int r = 0; r < KR; ++r) v[q][r] = YUE_FOLD_LD(src + (uint64_t)(q0 + q < c ? q0 + q : q0) * k + el[r]);
 #pragma unroll
-                for (unsigned q = 0; q < 4; ++q)
+                for (unsigned q = 0; q < STEP; ++q)
 #pragma unroll
                     for (int r = 0; r < KR; ++r) acc[r] = acc[r] + (q0 + q < c ? v[q][r] : 0.0f);
             }
