@@ -626,6 +626,9 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     if (round_events == 0 && (rc = default_round_events(c, tot[1] / c->nranks, &round_events))) return rc;
     int64_t ub = 1, group = 1;
     if ((rc = yue_epoch_plan(c->m, c->k, round_events, etot, c->nranks, &ub, &group, nullptr))) return rc;
+    // one GPU: nobody waits for the user rows of a group (a user's events all lie in one round, P[u] is not read again this epoch),
+    // so the differences are applied once behind the last round instead of group by group between the rounds
+    if (!yue_host::on_communicator(c)) group = std::max<int64_t>(1, (c->m + ub - 1) / ub);
     std::vector<int64_t> ublock;
     for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
     ublock.push_back(c->m); bounds.push_back(E);
