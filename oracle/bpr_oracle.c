@@ -255,6 +255,55 @@ int64_t orc_dependency_depth(const int32_t *u, const int32_t *i, const int32_t *
 
 
 /*
+ * A TIMING MODEL of the exact path's dataflow launch (yue_amd/csrc/chain_kernels.hpp), not a checker: `workers` wave groups
+ * claim the runs of equal consecutive users in stream order; a run costs `startup` before its first triplet; a triplet starts
+ * when its predecessor in the run is done and both item rows have arrived -- `hop` after the previous touch of the row finished
+ * when that touch belongs to another run, `hop_same` when it belongs to this run -- and takes `step`.  Returns the makespan in
+ * the unit of the cost arguments (tools/chain_model.py: which of step / hop / window bounds an epoch of a given stream).
+ */
+double orc_dataflow_model(const int32_t *u, const int32_t *i, const int32_t *j, int64_t T, int64_t n, int workers,
+                          double startup, double step, double hop, double hop_same, int64_t *hops_on_path_out) {
+    double *rq = (double *)calloc((size_t)n, sizeof(double)), *heap = (double *)calloc((size_t)workers, sizeof(double));
+    int32_t *hq = (int32_t *)calloc((size_t)n, sizeof(int32_t));      /* cross-run hops on the longest path into the row's last touch */
+    int64_t *owner = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+    double makespan = 0.0; int64_t hops_best = 0;
+    if (!rq || !heap || !hq || !owner) { free(rq); free(heap); free(hq); free(owner); return -1.0; }
+    for (int64_t r = 0; r < n; ++r) owner[r] = -1;
+    int64_t t = 0, run = 0;
+    while (t < T) {
+        int64_t e = t; while (e < T && u[e] == u[t]) ++e;
+        /* the worker that frees first takes the run (heap[0] = minimum) */
+        double f = heap[0] + startup; int32_t h = 0;
+        for (int64_t x = t; x < e; ++x) {
+            if (j[x] < 0) continue;
+            const int32_t rows[2] = { i[x], j[x] };
+            for (int q = 0; q < 2; ++q) {
+                const int32_t r = rows[q];
+                if (owner[r] < 0) continue;
+                const double ready = rq[r] + (owner[r] == run ? hop_same : hop);
+                if (ready > f) { f = ready; h = hq[r] + (owner[r] == run ? 0 : 1); }
+            }
+            f += step;
+            rq[i[x]] = rq[j[x]] = f; owner[i[x]] = owner[j[x]] = run; hq[i[x]] = hq[j[x]] = h;
+        }
+        if (f > makespan) { makespan = f; hops_best = h; }
+        /* replace the heap's minimum by this worker's new free time, sift down */
+        int k = 0; heap[0] = f;
+        for (;;) {
+            int a = 2 * k + 1, b = a + 1, s = k;
+            if (a < workers && heap[a] < heap[s]) s = a;
+            if (b < workers && heap[b] < heap[s]) s = b;
+            if (s == k) break;
+            double tmp = heap[s]; heap[s] = heap[k]; heap[k] = tmp; k = s;
+        }
+        t = e; ++run;
+    }
+    if (hops_on_path_out) *hops_on_path_out = hops_best;
+    free(rq); free(heap); free(hq); free(owner);
+    return makespan;
+}
+
+/*
  * Timing baseline only (bench.py cpu_baseline): the same loop run Hogwild-style by
  * `threads` threads, each over a contiguous slice of the triplet stream, racing on shared rows.
  * Not a checker: its result depends on the interleaving.

@@ -36,6 +36,7 @@ class Oracle(object):
         L.orc_bpr_round_deltas.restype = C.c_double
         L.orc_topn_scan.restype = C.c_int
         L.orc_dependency_depth.restype = C.c_int64
+        L.orc_dataflow_model.restype = C.c_double
 
     # -- samplers -------------------------------------------------------------
     def sample_python(self, seed, epochs, ev_u, n, indptr, indices, want_draws=False):
@@ -81,6 +82,14 @@ class Oracle(object):
         row_max = C.c_int64()
         depth = self.lib.orc_dependency_depth(_p(u, C.c_int32), _p(i, C.c_int32), _p(j, C.c_int32), C.c_int64(len(u)), C.c_int64(m), C.c_int64(n), C.byref(row_max))
         return int(depth), int(row_max.value)
+
+    def dataflow_model(self, u, i, j, n, workers, startup, step, hop, hop_same):
+        """Timing model of the exact path's dataflow launch (see orc_dataflow_model): (makespan, cross-run hops on its longest path)."""
+        u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
+        hops = C.c_int64()
+        t = self.lib.orc_dataflow_model(_p(u, C.c_int32), _p(i, C.c_int32), _p(j, C.c_int32), C.c_int64(len(u)), C.c_int64(n), C.c_int(workers),
+                                        C.c_double(startup), C.c_double(step), C.c_double(hop), C.c_double(hop_same), C.byref(hops))
+        return float(t), int(hops.value)
 
     def bpr_rounds(self, P, Q, u, i, j, round_ptr, lr, regU, regI):
         assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous

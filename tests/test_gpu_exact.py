@@ -132,22 +132,81 @@ def test_a_wave_that_cannot_get_its_row_gives_up_instead_of_hanging(dev):
     assert np.isfinite(dev.bpr_epoch(5, 0, 512, 0.02, 0.01, 0.01)[0])
 
 
+def _exact_epoch(dev, data, P0, Q0, seed, split, fast, epochs=1, xcd=0):
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    dev.set_option('epoch_exact', 1)
+    dev.set_option('chain_split', split)
+    dev.set_option('chain_fast', fast)
+    dev.set_option('chain_xcd', xcd)
+    try:
+        nll = [dev.bpr_epoch(seed, ep, 0, 0.02, 0.01, 0.01)[0] for ep in range(epochs)]
+    finally:
+        dev.set_option('epoch_exact', 0)
+        dev.set_option('chain_split', 0)
+        dev.set_option('chain_fast', 0)
+        dev.set_option('chain_xcd', 0)
+    return (nll,) + dev.get_factors()
+
+
 @pytest.mark.parametrize('m,n,d,k', [(3000, 2000, 20, 128), (5000, 64, 12, 64), (700, 900, 70, 10), (400, 300, 25, 200)])
-def test_two_wave_variant_is_bit_equal(dev, m, n, d, k):
-    """Option chain_split: a run walked by a pair of waves (memory side / dependency chain, hand-over through LDS) must produce
-    exactly the factors (and the loss) of the one-wave kernel (70 events per user: runs longer than one segment of 64)."""
+def test_three_wave_variant_is_bit_equal(dev, m, n, d, k):
+    """Option chain_split: a run walked by three waves (loads / dependency chain / stores, hand-over through LDS) must produce
+    exactly the factors (and the loss) of the one-wave kernel (70 events per user: runs longer than one segment of 64;
+    5000 users on 64 items: the ring of packets is full of rows that wait for the same group's own stores) -- on all XCDs with
+    write-through hand-offs, and with every working wave on ONE XCD and the rows handed over through its L2 (option chain_xcd)."""
     data, ev_u, P0, Q0 = _problem(m, n, d, k, 7)
-    res = []
-    for split in (0, 1):
-        dev.set_factors(P0, Q0)
-        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
-        dev.set_option('epoch_exact', 1)
-        dev.set_option('chain_split', split)
-        try:
-            nll = dev.bpr_epoch(9, 0, 0, 0.02, 0.01, 0.01)[0]
-        finally:
-            dev.set_option('epoch_exact', 0)
-            dev.set_option('chain_split', 0)
-        res.append((nll,) + dev.get_factors())
+    res = [_exact_epoch(dev, data, P0, Q0, 9, split, 0, epochs=2, xcd=xcd) for split, xcd in ((0, 0), (1, 0), (1, 1))]
     # (the loss is a sum of per-wave partials added in whatever order the waves finish)
-    assert abs(res[0][0] - res[1][0]) <= 1e-12 * abs(res[0][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    for other in res[1:]:
+        assert all(abs(a - b) <= 1e-12 * abs(a) for a, b in zip(res[0][0], other[0]))
+        assert np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+    print('one XCD: %d waves stayed' % dev.get_option('chain_last_waves'))
+
+
+def test_three_wave_replay_of_an_interleaved_stream_is_bit_equal(dev):
+    """The general stream (users come back: user rows versioned per run, skipped triplets, items repeated inside a run) through
+    the three-wave kernel lands on the one-wave kernel's factors."""
+    rs = np.random.RandomState(79)
+    m, n, k, T = 300, 500, 128, 40000
+    P0, Q0 = synth.init_factors(m, n, k, 80)
+    u = rs.randint(0, m, size=T).astype(np.int32)
+    u[2000:2300] = 11
+    idx = np.arange(0, T - 1, 3)
+    u[idx] = u[idx + 1]
+    i = (n * rs.rand(T) ** 2).astype(np.int32)
+    j = rs.randint(0, n, size=T).astype(np.int32)
+    j[j == i] = (i[j == i] + 1) % n
+    j[rs.rand(T) < 0.01] = -1
+    res = []
+    for split, xcd in ((0, 0), (1, 0), (1, 1)):
+        dev.set_factors(P0, Q0)
+        dev.set_option('chain_split', split)
+        dev.set_option('chain_xcd', xcd)
+        try:
+            nll = dev.bpr_replay(u, i, j, 0.03, 0.02, 0.01)
+        finally:
+            dev.set_option('chain_split', 0)
+            dev.set_option('chain_xcd', 0)
+        res.append((nll,) + dev.get_factors())
+    for other in res[1:]:
+        assert abs(res[0][0] - other[0]) <= 1e-12 * abs(res[0][0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+
+
+@pytest.mark.parametrize('split', [0, 1])
+@pytest.mark.parametrize('m,n,d,k', [(3000, 2000, 20, 128), (5000, 64, 12, 64), (700, 900, 70, 10), (400, 300, 25, 200), (20000, 5000, 20, 128)])
+def test_fast_coefficient_stays_within_the_north_star_tolerance(dev, orc, split, m, n, d, k):
+    """Option chain_fast: the step's coefficient c = fp32(lr (1 - sigmoid(x))) in single precision and the margin as ONE 64-lane
+    sum of p . (qi - qj) -- not bit-equal to the reference's arithmetic, but within BASELINE.json's 1e-5 of the sequential
+    oracle after two epochs (the loss is still summed from double-precision sigmoids of the margins)."""
+    data, ev_u, P0, Q0 = _problem(m, n, d, k, 31 + k)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    js = [dev.sample_negatives(5, ep) for ep in range(2)]
+    nll, P, Q = _exact_epoch(dev, data, P0, Q0, 5, split, 1, epochs=2)
+    Po, Qo = P0.copy(), Q0.copy()
+    for ep in range(2):
+        nll_o = orc.bpr_sequential(Po, Qo, ev_u, data['ev_i'], js[ep], 0.02, 0.01, 0.01)
+        assert abs(nll[ep] - nll_o) <= 1e-6 * abs(nll_o)
+    print('fast coefficient (split %d): rel P %.2e Q %.2e; bit-equal to the oracle: P %.4f Q %.4f' % (split, rel_err(P, Po), rel_err(Q, Qo), np.mean(P == Po), np.mean(Q == Qo)))
+    assert rel_err(P, Po) < 1e-5 and rel_err(Q, Qo) < 1e-5

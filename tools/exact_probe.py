@@ -35,8 +35,8 @@ def main():
         t0 = time.perf_counter()
         nll, sp, sq = dev.bpr_epoch(20260003, ep, 0, 0.02, 0.01, 0.01)
         dt = time.perf_counter() - t0
-        print('%s exact epoch %d: %.1f ms  %.3e triplets/s  nll/triplet %.5f  (runs %d, waves %d)' % (
-            name, ep, 1e3 * dt, E / dt, nll / E, dev.get_option('chain_last_runs'), dev.get_option('chain_last_waves')), flush=True)
+        print('%s exact epoch %d: %.1f ms  %.3e triplets/s  nll/triplet %.5f  (runs %d, waves %d; the dataflow launch alone %.1f ms)' % (
+            name, ep, 1e3 * dt, E / dt, nll / E, dev.get_option('chain_last_runs'), dev.get_option('chain_last_waves'), 1e-3 * dev.get_option('chain_last_us')), flush=True)
     dev.set_option('epoch_exact', 0)
     if '--replay' in os.environ.get('PROBE', ''):
         j = dev.sample_negatives(20260003, 0)

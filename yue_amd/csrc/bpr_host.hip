@@ -762,6 +762,10 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "replay_levels") *value = c->opt_replay_levels;
     else if (key == "chain_waves") *value = c->opt_chain_waves;
     else if (key == "chain_split") *value = c->opt_chain_split;
+    else if (key == "chain_fast") *value = c->opt_chain_fast;
+    else if (key == "chain_xcd") *value = c->opt_chain_xcd;
+    else if (key == "chain_last_us") *value = c->chain_kernel_us;
+    else if (key == "chain_ring") *value = c->opt_chain_ring;
     else if (key == "chain_spin") *value = c->opt_chain_spin;
     else if (key == "chain_last_runs") *value = c->chain_runs;          // last exact launch: runs walked, waves launched
     else if (key == "chain_last_waves") *value = c->chain_waves;
@@ -789,6 +793,9 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "epoch_exact") { c->opt_epoch_exact = value != 0; return YUE_OK; }
     if (key == "replay_levels") { c->opt_replay_levels = value != 0; return YUE_OK; }
     if (key == "chain_split") { c->opt_chain_split = value != 0; return YUE_OK; }
+    if (key == "chain_fast") { c->opt_chain_fast = value != 0; return YUE_OK; }
+    if (key == "chain_xcd") { c->opt_chain_xcd = value != 0; return YUE_OK; }
+    if (key == "chain_ring") { if (value != 0 && value != 8 && value != 16) return fail(YUE_ERR_ARG, "yue_set_option: chain_ring must be 0, 8 or 16"); c->opt_chain_ring = (int)value; return YUE_OK; }
     if (key == "chain_waves") { if (value < 0 || value > 8) return fail(YUE_ERR_ARG, "yue_set_option: chain_waves must be 0..8"); c->opt_chain_waves = (int)value; return YUE_OK; }
     if (key == "chain_spin") { if (value < 0 || value > 0x7fffffff) return fail(YUE_ERR_ARG, "yue_set_option: chain_spin out of range"); c->opt_chain_spin = value; return YUE_OK; }
     if (key == "round_bucket") { c->opt_round_bucket = value != 0; return YUE_OK; }

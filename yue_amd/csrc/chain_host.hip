@@ -76,33 +76,62 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     HIPCHK(hipMemsetAsync(c->ch_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
     a.stats = c->ch_stats.p;
 #endif
-    // One persistent launch of resident waves only (a wave that is not resident cannot be waited for).  Default: ONE wave per
-    // SIMD (one workgroup of four per CU, 1,024 waves on MI355X): the epoch's time is its longest chain of dependent triplets
-    // times the latency of a step, and a wave alone on its SIMD has the shortest step (measured on BASELINE config 3:
-    // 913 ms per epoch with 1,024 waves, 1,131 ms with 3,072; option chain_waves = workgroups per CU).
+    // One persistent launch of resident waves only (a wave that is not resident cannot be waited for).  The epoch's time is its
+    // longest chain of dependent triplets times the latency of a step, and a wave alone on its SIMD has the shortest step
+    // (measured on BASELINE config 3 with k_bpr_chain: 913 ms per epoch with 1,024 waves, 1,131 ms with 3,072), so the default
+    // is ONE workgroup per CU (option chain_waves = workgroups per CU):
+    //   chain_split = 1 (default): k_bpr_chain3, a workgroup = three waves (loads / chain / stores) walking one run;
+    //   chain_split = 0: k_bpr_chain, a workgroup = four waves, each walking a run of its own.
+    // chain_fast = 1: single-precision coefficient and one 64-lane sum per triplet (within 1e-5 of the reference, not bit-equal).
     int per_cu = 0, cus = 0;
     const int kr = kr_of(k);
-    const dim3 block(256);
-    dim3 grid(1);
-    // ring of 8 triplets per wave (4 for k > 128: register budget)
-#define YUE_CHAIN_RUN(KR_, PV_, G_)                                                                                                   \
-    do {                                                                                                                                \
-        if (c->opt_chain_split) {                                                                                                       \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain2<KR_, PV_, G_>, 256, 0));                     \
-            per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 1));                                   \
-            grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 1) / 2)));                        \
-            hipLaunchKernelGGL((yue::k_bpr_chain2<KR_, PV_, G_>), grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p); \
-        } else {                                                                                                                        \
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yue::k_bpr_chain<KR_, PV_, G_>, 256, 0));                          \
-        per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : 1));                                       \
-        grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, (R + 3) / 4)));                            \
-        hipLaunchKernelGGL((yue::k_bpr_chain<KR_, PV_, G_>), grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p);  \
-        }                                                                                                                               \
-    } while (0)
+    dim3 block(256), grid(1);
+    int waves_per_block = 4;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    if (ord_u) { if (kr == 1) YUE_CHAIN_RUN(1, true, 8); else if (kr == 2) YUE_CHAIN_RUN(2, true, 8); else YUE_CHAIN_RUN(4, true, 4); }
-    else { if (kr == 1) YUE_CHAIN_RUN(1, false, 8); else if (kr == 2) YUE_CHAIN_RUN(2, false, 8); else YUE_CHAIN_RUN(4, false, 4); }
+    bool one_xcd = false, allow_one_xcd = true;
+    auto launch = [&](auto kernel, int threads, int64_t runs_per_block) -> int {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
+        per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : (one_xcd ? 2 : 1)));
+        block = dim3((unsigned)threads);
+        // (one XCD: a workgroup in eight stays, and the XCD has an eighth of the CUs -- the same grid size for per_cu per CU of it)
+        grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, one_xcd ? (int64_t)per_cu * cus : (R + runs_per_block - 1) / runs_per_block)));
+        HIPCHK(hipEventRecord(c->ev_chain0, c->stream));
+        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, a, ev_i, ev_j, c->ch_ord_i.p, c->ch_ord_j.p);
+        HIPCHK(hipEventRecord(c->ev_chain1, c->stream));
+        return YUE_OK;
+    };
+    if (!c->ev_chain0) { HIPCHK(hipEventCreate(&c->ev_chain0)); HIPCHK(hipEventCreate(&c->ev_chain1)); }
+    a.xcd = 0u; a.groups = c->ch_ctl.p + 3;
+    // ring of 8 prefetched triplets per wave (k_bpr_chain at k > 128: 4, register budget)
+#define YUE_CHAIN3(KR_, PV_, G_, X_) (c->opt_chain_fast ? launch(yue::k_bpr_chain3<KR_, PV_, G_, true, X_>, 192, 1) : launch(yue::k_bpr_chain3<KR_, PV_, G_, false, X_>, 192, 1))
+#define YUE_CHAIN_RUN(KR_, PV_, G1_)                                                                                    \
+    do {                                                                                                                  \
+        if (c->opt_chain_split) {                                                                                         \
+            waves_per_block = 3;                                                                                          \
+            one_xcd = c->opt_chain_xcd != 0 && allow_one_xcd;                                                                           \
+            if (c->opt_chain_ring == 16 && KR_ <= 2) rc = one_xcd ? YUE_CHAIN3(KR_, PV_, (KR_ <= 2 ? 16 : 8), true) : YUE_CHAIN3(KR_, PV_, (KR_ <= 2 ? 16 : 8), false); \
+            else rc = one_xcd ? YUE_CHAIN3(KR_, PV_, 8, true) : YUE_CHAIN3(KR_, PV_, 8, false);                           \
+        } else {                                                                                                          \
+            rc = c->opt_chain_fast ? launch(yue::k_bpr_chain<KR_, PV_, G1_, true>, 256, 4)                                \
+                                   : launch(yue::k_bpr_chain<KR_, PV_, G1_, false>, 256, 4);                              \
+        }                                                                                                                 \
+    } while (0)
+    for (;;) {
+        if (ord_u) { if (kr == 1) YUE_CHAIN_RUN(1, true, 8); else if (kr == 2) YUE_CHAIN_RUN(2, true, 8); else YUE_CHAIN_RUN(4, true, 4); }
+        else { if (kr == 1) YUE_CHAIN_RUN(1, false, 8); else if (kr == 2) YUE_CHAIN_RUN(2, false, 8); else YUE_CHAIN_RUN(4, false, 4); }
+        if (rc || !one_xcd) break;
+        // one XCD: did any workgroup land on it?  (Placement is the dispatcher's business; with none, nothing has been touched
+        // and the launch is repeated on all XCDs with write-through hand-offs.)
+        unsigned long long stayed = 0;
+        HIPCHK(hipMemcpyAsync(&stayed, c->ch_ctl.p + 3, sizeof stayed, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->chain_groups = (int64_t)stayed;
+        if (stayed > 0) break;
+        allow_one_xcd = false;
+    }
 #undef YUE_CHAIN_RUN
+#undef YUE_CHAIN3
+    if (rc) return rc;
     const int64_t blocks = grid.x;
     hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, c->ch_Qv.p, c->Q.p, n, k);
     if (ord_u) hipLaunchKernelGGL(yue::k_chain_unpack, dim3(2048), dim3(256), 0, c->stream, c->ch_Pv.p, c->P.p, m, k);
@@ -116,14 +145,15 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
         unsigned long long h[8];
         HIPCHK(hipMemcpy(h, c->ch_stats.p, sizeof h, hipMemcpyDeviceToHost));
         if (c->opt_chain_split)
-            fprintf(stderr, "[chain2 stats] wave C: %.0f cycles of work and %.0f cycles of waiting for rows per packet (%llu packets); wave M: %.0f cycles waiting for a coefficient (%llu triplets)\n",
-                    h[1] ? (double)h[0] / h[1] : 0.0, h[3] ? (double)h[2] / h[3] : 0.0, h[1], h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
+            fprintf(stderr, "[chain3 stats] wave C: %.0f cycles of work per triplet, %.0f waiting for its rows (%llu triplets); wave L: %.0f cycles per step without a wait (%llu steps, %llu more waited for a row); wave S: %.0f cycles from a packet to its coefficient\n",
+                    h[1] ? (double)h[0] / h[1] : 0.0, h[1] ? (double)h[2] / h[1] : 0.0, h[1], h[4] ? (double)h[3] / h[4] : 0.0, h[4], h[7], h[6] ? (double)h[5] / h[6] : 0.0);
         else
         fprintf(stderr, "[chain stats] steps without a wait: %llu, %.0f cycles each; steps that waited: %llu (%.2f %%), %.0f cycles each; per run outside the steps: %.0f cycles (%llu runs)\n",
                 h[1], h[1] ? (double)h[0] / h[1] : 0.0, h[3], 100.0 * h[3] / (double)(h[1] + h[3] + 1e-9), h[3] ? (double)h[2] / h[3] : 0.0, h[5] ? (double)h[4] / h[5] : 0.0, h[5]);
     }
 #endif
-    c->chain_runs = R; c->chain_waves = blocks * 4;
+    c->chain_runs = R; c->chain_waves = (one_xcd ? c->chain_groups : blocks) * waves_per_block;
+    { float ms = 0.0f; HIPCHK(hipEventElapsedTime(&ms, c->ev_chain0, c->ev_chain1)); c->chain_kernel_us = (int64_t)(1e3 * ms); }
     if (st) return fail(YUE_ERR_HIP, std::string("exact path: a wave gave up waiting for a row (") + ((st & 2u) ? "a row's version ran past a waiting touch" : "spin limit") +
                                     "): internal error, the factors on the device are not usable");
     return YUE_OK;

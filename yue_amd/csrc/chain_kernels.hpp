@@ -49,6 +49,8 @@ struct ChainArgs {
     float ru, ri;
     double lr;
     uint32_t spin_limit;         // polls a wave spends on ONE wait before it gives up (guards against a hung GPU)
+    uint32_t xcd;                // k_bpr_chain3<.., ONE_XCD>: the XCD whose workgroups do the work (the others leave at once)
+    unsigned long long *groups;  // ... and how many workgroups stayed
 #ifdef YUE_CHAIN_STATS
     unsigned long long *stats;   // diagnostic build only (make chainstats): [0] cycles in steps without a wait, [1] such steps,
                                  // [2] cycles in steps that waited, [3] such steps, [4] cycles per run outside the steps, [5] runs
@@ -158,6 +160,41 @@ __device__ __forceinline__ double chain_rcp(double d) {
     return __builtin_fma(e, y, y);
 }
 
+// sigmoid of the fp32 margin in double (qmath.py:115-116), as every exact kernel and the loss use it
+__device__ __forceinline__ double chain_sigmoid(float x) {
+    const double xd = (double)x;
+    if (__builtin_fabs(xd) <= 700.0) return chain_rcp(1.0 + chain_exp(-xd));
+    return 1.0 / (1.0 + exp(-xd));
+}
+// fp32(lr (1 - sigmoid(x))) = lr / (1 + e^x) in SINGLE precision -- the short form of the step's coefficient (option
+// chain_fast): five instructions on the dependency chain (v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul) instead of ~35
+// double-precision ones.  Not bit-equal to the reference's value: v_exp_f32 and v_rcp_f32 are good to 1 ulp, the rounding of
+// x log2 e adds |x| * 6e-8 relative -- a few ulp of c for the margins that occur, against north_star's 1e-5 on the factors
+// (measured: tests/test_gpu_exact.py, tests/test_gpu_baseline_configs.py).
+__device__ __forceinline__ float chain_coef_fast(float x, float lr) {
+    // (an infinite e^x gives 0, a vanishing one gives lr, a NaN margin stays a NaN -- the reference aborts on a NaN loss)
+    return lr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f));
+}
+
+// Sum over the 64 lanes in NO particular order (option chain_fast only; wave_sum keeps the oracle's order): four DPP-fused
+// adds give every lane its row's sum, row_bcast15 / row_bcast31 carry the row sums up, lane 63 holds the total.
+__device__ __forceinline__ float wave_sum_any(float v) {
+    v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v);      // row_half_mirror
+    v = v + dpp_mov<0x140>(v);      // row_mirror
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1, 3
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2, 3
+    return rdlane(v, 63);
+}
+
+// An SGPR written by the vector ALU (v_readlane, v_readfirstlane) may be read by a vector-memory instruction only 5 wait
+// states later.  The compiler counts them for its own instructions but does not see into inline assembly: every scalar
+// operand of the assembly loads / stores below (descriptors, row offsets) that can come out of the vector ALU passes through
+// here first.  (tests/test_asm_hazards.py checks the listing for it.)
+__device__ __forceinline__ void vmem_sgpr_guard(unsigned &s0) { asm volatile("s_nop 4" : "+s"(s0)); }
+__device__ __forceinline__ void vmem_sgpr_guard(unsigned &s0, unsigned &s1) { asm volatile("s_nop 4" : "+s"(s0), "+s"(s1)); }
+
 // One wave per run.  Lane l holds elements 64 r + l (r < KR) of the three rows, as everywhere in the training kernels.
 //
 // The wave walks its run as a software pipeline over a ring of G slots: while triplet t is computed, the item rows of
@@ -173,11 +210,14 @@ __device__ __forceinline__ double chain_rcp(double d) {
 // the slot's turn comes: s_waitcnt vmcnt((G - 1) * 4 GR) is exact.  Anything issued in between (re-polls of the slow path)
 // only adds younger operations or drains: the count stays a lower bound.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vmem_sgpr_guard(i32x4 &rs) { asm volatile("s_nop 4" : "+s"(rs)); }
 
 struct Gran {
     typedef u32x2 reg; typedef float val;
     static __device__ __forceinline__ void load(reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(d) : "v"(vo), "s"(rs), "s"(so) : "memory"); }
     static __device__ __forceinline__ void store(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory"); }
+    // the same store left in the XCD's L2 (no write-through): only for a launch whose waves ALL sit behind one L2 (k_bpr_chain3<.., ONE_XCD>)
+    static __device__ __forceinline__ void store_l2(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory"); }
     static __device__ __forceinline__ val value(const reg &d) { return __builtin_bit_cast(float, d.x); }
     static __device__ __forceinline__ bool is(const reg &d, unsigned want) { return d.y == want; }
     static __device__ __forceinline__ unsigned version(const reg &d) { return d.y; }
@@ -198,7 +238,7 @@ __device__ __forceinline__ void row_wait_all(R (&g)[GR]) {
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) :: "memory");
 }
 
-template <int KR, bool PVER, int G>
+template <int KR, bool PVER, int G, bool FAST>
 __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                    const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
     constexpr int GR = KR, GB = 8;                       // granules per lane and row, granule bytes
@@ -217,8 +257,8 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
     i32x4 rq;                                            // buffer descriptor of Qv as plain words, for the assembly operands
     { const uint64_t qa = (uint64_t)a.Qv; rq.x = (int)(uint32_t)qa; rq.y = (int)((uint32_t)(qa >> 32) & 0xffffu); rq.z = qrec; rq.w = kRsrcFlags; }
     double nl = 0.0;                                     // per-lane partial of sum -log(s)
-    double sv = 1.0;                                     // lane q keeps the sigmoid of the q-th triplet since the last flush
-    unsigned nsv = 0;                                    // (the logs are taken 64 at a time, off the dependency chain)
+    float xs = 0.0f;                                     // lane q keeps the margin of the q-th triplet since the last flush
+    unsigned nsv = 0;                                    // (sigmoid and log of the loss are taken 64 at a time, off the dependency chain)
     uint64_t wave_slot = 0;
     bool dead = false;
     YUE_CS(unsigned long long cs_fast = 0, cs_nfast = 0, cs_slow = 0, cs_nslow = 0, cs_run = 0, cs_nrun = 0;)
@@ -260,7 +300,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
         }
     };
     auto flush_logs = [&]() {
-        if ((unsigned)lane < nsv) nl += -log(sv);                    // BPR.py:58
+        if ((unsigned)lane < nsv) nl += -log(chain_sigmoid(xs));     // BPR.py:58
         nsv = 0;
     };
 
@@ -284,9 +324,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
             const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * (row_bytes / 4u));
             rp.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)pa); rp.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xffffu));
             rp.z = (int)row_bytes; rp.w = kRsrcFlags;
-            // v_readfirstlane has just written two words of the descriptor: a vector-memory instruction may read an SGPR a
-            // VALU instruction wrote only 5 wait states later, and the compiler does not see into the assembly below
-            asm volatile("s_nop 4" : "+s"(rp));
+            vmem_sgpr_guard(rp);                                     // v_readfirstlane has just written two words of the descriptor
             pver = a.ord_u[run];
             greg g[GR];
 #pragma unroll
@@ -316,7 +354,8 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
             // loads of one slot: 2 GR ring loads, real ones for an event with a negative, out-of-range dummies otherwise
             auto fill = [&](int s, int i_, int j_) {
                 const bool live = j_ >= 0;
-                const unsigned oi = live ? (unsigned)i_ * row_bytes : 0u, oj = live ? (unsigned)j_ * row_bytes : 0u;
+                unsigned oi = live ? (unsigned)i_ * row_bytes : 0u, oj = live ? (unsigned)j_ * row_bytes : 0u;
+                vmem_sgpr_guard(oi, oj);
 #pragma unroll
                 for (int q = 0; q < GR; ++q) {
                     const unsigned v = live ? vo[q] : v_oob;
@@ -343,7 +382,8 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                     bool done = false;
                     if (tj >= 0 && !dead) {                          // (wave-uniform) an event of the run with a negative
                         const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, ol + s), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, ol + s);
-                        const unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)tj * row_bytes;
+                        unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)tj * row_bytes;
+                        vmem_sgpr_guard(oi, oj);
                         bool ok = true;
                         if (!all_mine(wj, gj[s])) { ok = acquire_slow(rq, oj, wj, gj[s]); YUE_CS(cs_waited = true;) }
                         if (ok && !all_mine(wi, gi[s])) { ok = acquire_slow(rq, oi, wi, gi[s]); YUE_CS(cs_waited = true;) }
@@ -352,16 +392,21 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                             gval qi[GR], qj[GR];
 #pragma unroll
                             for (int q = 0; q < GR; ++q) { qi[q] = GT::value(gi[s][q]); qj[q] = GT::value(gj[s][q]); }
-                            // per-lane partials in element order 64 r + l, r ascending (oracle/bpr_oracle.c: dot64)
-                            float ai = 0.0f, aj = 0.0f;
+                            float x;
+                            if (FAST) {
+                                // option chain_fast (within 1e-5, not bit-equal): one 64-lane sum of p . (qi - qj)
+                                float acc = 0.0f;
 #pragma unroll
-                            for (int q = 0; q < GR; ++q) { const gval mi = p[q] * qi[q], mj = p[q] * qj[q]; ai = ai + mi; aj = aj + mj; }
-                            const float x = wave_sum(ai) - wave_sum(aj);             // BPR.py:50, fp32 margin
-                            const double xd = (double)x;
-                            double sg;
-                            if (__builtin_fabs(xd) <= 700.0) sg = chain_rcp(1.0 + chain_exp(-xd)); // qmath.py:115-116
-                            else sg = 1.0 / (1.0 + exp(-xd));
-                            const float c = (float)(a.lr * (1.0 - sg));
+                                for (int q = 0; q < GR; ++q) { const gval dq = qi[q] - qj[q]; acc = q == 0 ? p[0] * dq : __builtin_fmaf(p[q], dq, acc); }
+                                x = wave_sum_any(acc);
+                            } else {
+                                // per-lane partials in element order 64 r + l, r ascending (oracle/bpr_oracle.c: dot64)
+                                float ai = 0.0f, aj = 0.0f;
+#pragma unroll
+                                for (int q = 0; q < GR; ++q) { const gval mi = p[q] * qi[q], mj = p[q] * qj[q]; ai = ai + mi; aj = aj + mj; }
+                                x = wave_sum(ai) - wave_sum(aj);                     // BPR.py:50, fp32 margin
+                            }
+                            const float c = FAST ? chain_coef_fast(x, (float)a.lr) : (float)(a.lr * (1.0 - chain_sigmoid(x)));   // qmath.py:115-116
 #pragma unroll
                             for (int q = 0; q < GR; ++q) {
                                 // BPR.py:51-57 (as bpr_elem)
@@ -375,7 +420,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                                 GT::store(GT::make(qi1 - ra, wi + 1u), vo[q], rq, oi);   // the positive's row first: the hotter of the two
                                 GT::store(GT::make(qj1 - rb, wj + 1u), vo[q], rq, oj);
                             }
-                            sv = (unsigned)lane == nsv ? sg : sv;
+                            xs = (unsigned)lane == nsv ? x : xs;
                             if (++nsv == 64u) flush_logs();
                             done = true;
                         }
@@ -412,127 +457,297 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The same dataflow with the work of a run split over TWO waves (a pair on two SIMDs of one CU).  A lone wave issues its
-// instructions one after the other, so the time of a step is the number of its instructions: ~200 in k_bpr_chain, of which
-// the next triplet of the run only needs the margin, the sigmoid and the new user row (~85).
-//   wave M ("memory"): everything of k_bpr_chain except the margin -- claim, headers, the ring of prefetched rows with its
-//       counted waits, version checks and polling, the item-row updates and their granule stores, the user row at the end.
-//       It PUBLISHES the two rows of the next triplet in LDS before it waits for the coefficient of the current one;
-//   wave C ("chain"): reads published rows from LDS, computes the two dots, the sigmoid and c = fp32(lr (1 - s)), hands c back
-//       through LDS, updates its copy of the user row, keeps the loss.  It never touches global memory.
-// Both waves keep the user row and update it with the same instructions, so only c crosses back.  Packets M -> C carry a
-// sequence number that grows over the whole launch (slot = number mod kPairRing): a stale slot never matches.  LDS serves a
-// wave's operations in order, so "rows, then tag" written by M and "tag, then rows" read by C need no fence.
+// The same dataflow with the work of a run split over THREE waves of one workgroup (one wave per SIMD of a CU).  A lone wave
+// issues its instructions one after the other, so the latency of a step of k_bpr_chain is the number of its instructions
+// (~250), of which the next triplet of the run needs only the margin, the sigmoid and the new user row.  Here
+//   wave L ("loads"):  claims runs, keeps the headers, the ring of prefetched granule rows with its counted waits, the version
+//       checks and the polling; a row pair that carries its ordinals is PUBLISHED to the other two waves through LDS;
+//   wave C ("chain"):  reads published rows from LDS, computes the margin, the sigmoid and c = fp32(lr (1 - s)), hands c on
+//       through LDS, updates its copy of the user row, keeps the loss.  No global memory, no headers, no version checks: the
+//       dependency chain of a run and nothing else;
+//   wave S ("stores"): takes the published rows and c, applies the reference's update to the two item rows (and to its own
+//       copy of the user row: same instructions as wave C, same values), stores the granules with version + 1, and the
+//       user row as soon as the run's end packet arrives.
+// (Round 3's two-wave split left the memory side as long as the chain side: no gain.  With the memory side split in two
+// the chain wave alone sets the step.)
+// Packets L -> C, S carry a sequence number that grows over the whole launch (slot = number mod kTrioRing): a stale slot
+// never matches.  Every word of the LDS mailboxes exists once per lane (lane l reads and writes word l): no exec masking, no
+// broadcast; LDS serves a wave's operations in order, so "rows, then tag" written by L and "tag, then rows" read by C and S
+// need no fence, and a wave that has been answered (coefficient from C, progress word from S) knows the other side's reads
+// of the slot are done.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int kPairRing = 8;
-constexpr unsigned kPktEvent = 0u, kPktStart = 1u, kPktExit = 2u;
+constexpr int kTrioRing = 16;
+constexpr unsigned kPktEvent = 0u, kPktStart = 1u, kPktExit = 2u, kPktEnd = 3u;
 
 template <int KR>
-struct PairBox {
-    float rows[kPairRing][2 * KR][64];     // event: qi[0..KR), qj[0..KR); start: the user row in [0..KR)
-    unsigned tag[kPairRing];               // (sequence number << 2) | packet type
-    unsigned cbits[kPairRing];             // the coefficient of the slot's triplet
-    unsigned cseq[kPairRing];              // sequence number it belongs to
+struct TrioBox {
+    static constexpr int ROWS = KR == 2 ? 8 : 2 * KR + 2;               // (k <= 128: a slot of 2 KB, its address is a shift)
+    static constexpr int META = 2 * KR, TAG = 2 * KR + 1;
+    float pkt[kTrioRing][ROWS][64];        // event: qi[0..KR), qj[KR..2KR); start: the user row in [0..KR); then meta, tag
+    unsigned cw[kTrioRing][2][64];         // from wave C: [0] coefficient of the slot's triplet, [1] sequence number it answers
+    unsigned sdone[64];                    // from wave S: last packet it is done with (L may reuse the slot kTrioRing later)
 };
+static_assert(sizeof(TrioBox<4>) <= 64 * 1024, "static LDS");
 
-// LDS words shared by the two waves of a pair: relaxed workgroup-scope atomics (plain ds_read / ds_write, never hoisted or
+// LDS words shared by the waves of a group: relaxed workgroup-scope atomics (plain ds_read / ds_write, never hoisted or
 // merged by the compiler, no waits on the vector-memory queue) between compiler barriers; the LDS keeps a wave's operations in order.
 __device__ __forceinline__ unsigned lds_get(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_put(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ float lds_getf(const float *p) { return __builtin_bit_cast(float, lds_get(reinterpret_cast<const unsigned *>(p))); }
-__device__ __forceinline__ void lds_putf(float *p, float v) { lds_put(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v)); }
+__device__ __forceinline__ unsigned lds_get(const float *p) { return lds_get(reinterpret_cast<const unsigned *>(p)); }
+__device__ __forceinline__ void lds_put(float *p, unsigned v) { lds_put(reinterpret_cast<unsigned *>(p), v); }
+__device__ __forceinline__ float lds_getf(const float *p) { return __builtin_bit_cast(float, lds_get(p)); }
+__device__ __forceinline__ float lds_getf(const unsigned *p) { return __builtin_bit_cast(float, lds_get(p)); }
+__device__ __forceinline__ void lds_putf(float *p, float v) { lds_put(p, __builtin_bit_cast(unsigned, v)); }
+__device__ __forceinline__ void lds_putf(unsigned *p, float v) { lds_put(p, __builtin_bit_cast(unsigned, v)); }
+__device__ __forceinline__ bool all_lanes(bool b) { return __builtin_amdgcn_ballot_w64(!b) == 0ull; }
+// v with lane L replaced by the wave-uniform s (v_writelane_b32; this compiler has no builtin for it)
+template <int L> __device__ __forceinline__ unsigned write_lane(unsigned v, unsigned s) { asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L)); return v; }
 
-template <int KR, bool PVER, int G>
-__global__ void __launch_bounds__(256) k_bpr_chain2(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
+// ONE_XCD: every hand-off of a row between two waves costs a round trip to the memory side (a write-through store drops the
+// line from L2, the reader's L1-bypassing load then misses L2): ~1.2 us per hop, and as much for every prefetched row that
+// turns out stale.  The L2 of ONE XCD is coherent for the 32 CUs in front of it, so a launch whose working
+// waves all sit on one XCD can hand rows over through that L2: plain stores (the line stays in L2), sc1 loads (past the
+// reader's L1, served by L2).  The grid is 8 x the wanted groups; a workgroup reads its XCD from the hardware register and
+// leaves at once unless it is the chosen one (workgroups are dealt round-robin over the XCDs; nothing depends on that being
+// exact: whoever stays works, the host checks that somebody did).
+template <int KR, bool PVER, int G, bool FAST, bool ONE_XCD>
+__global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                     const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
     constexpr int GR = KR, GB = 8;
     typedef Gran GT;
     typedef typename GT::reg greg;
-    __shared__ PairBox<KR> boxes[2];
+    typedef TrioBox<KR> Box;
+    constexpr int TAG = Box::TAG, META = Box::META;
+    __shared__ Box box;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    PairBox<KR> &box = boxes[wave >> 1];
-    if ((wave & 1) == 0 && lane < kPairRing) { box.tag[lane] = 0u; box.cseq[lane] = 0u; }
+    if (ONE_XCD) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((xcc & 15u) != a.xcd) return;                // (the whole workgroup: it sits on one XCD)
+        if (threadIdx.x == 0) atomicAdd(a.groups, 1ull);
+    }
+    for (int t = threadIdx.x; t < kTrioRing * 64; t += 192) { box.pkt[t >> 6][TAG][t & 63] = 0.0f; box.cw[t >> 6][1][t & 63] = 0u; }
+    if (threadIdx.x < 64) box.sdone[threadIdx.x] = 0u;
     __syncthreads();
+    const unsigned k = (unsigned)a.k;
+    const unsigned row_bytes = (unsigned)GR * 64u * GB;  // granule rows
+    // every wait of waves C and S ends when wave L publishes; wave L's own waits are bounded by the spin limit.  The bound
+    // below only guards against a protocol error: a wave that has slept this often sets the status word and leaves.
+    constexpr uint32_t kIdleLimit = 1u << 30;
+    uint32_t idle = 0;
+    auto nap = [&]() -> bool {                           // false: give up (status set by somebody, or the idle bound)
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_expect((++idle & 0xfffu) == 0u, 0)) {
+            if (idle >= kIdleLimit) { if (lane == 0) atomicOr(a.status, 4u); return false; }
+            if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        }
+        return true;
+    };
 
-    if ((wave & 1) == 0) {
+    if (wave == 1) {
         // ---------------------------------------------------------------- wave C: margin, sigmoid, coefficient, user row, loss
         float p[KR];
 #pragma unroll
         for (int r = 0; r < KR; ++r) p[r] = 0.0f;
-        double nl = 0.0, sv = 1.0;
+        double nl = 0.0;
+        float xs = 0.0f;                                 // lane q keeps the margin of the q-th triplet since the last flush
         unsigned nsv = 0, seq = 1;
-        YUE_CS(unsigned long long cs_work = 0, cs_wait = 0, cs_n = 0;)
-        for (;;) {
-            const unsigned slot = seq & (kPairRing - 1);
-            unsigned tg;
-            YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter();)
-            while (((tg = lds_get(&box.tag[slot])) >> 2) != seq) __builtin_amdgcn_s_sleep(1);
+        unsigned tg;
+        float d[2 * KR];
+        const float lrf = (float)a.lr;
+        auto fetch = [&](unsigned q) {                   // tag first, then the rows: a matching tag vouches for the rows read behind it
+            const unsigned slot = q & (kTrioRing - 1);
+            tg = lds_get(&box.pkt[slot][TAG][lane]);
             asm volatile("" ::: "memory");
-            YUE_CS(const unsigned long long cs_t1 = __builtin_readcyclecounter(); cs_wait += cs_t1 - cs_t0;)
-            const unsigned type = tg & 3u;
-            if (type == kPktExit) break;
-            float d[2 * KR];
 #pragma unroll
-            for (int r = 0; r < 2 * KR; ++r) d[r] = lds_getf(&box.rows[slot][r][lane]);
-            if (type == kPktStart) {
+            for (int r = 0; r < 2 * KR; ++r) d[r] = lds_getf(&box.pkt[slot][r][lane]);
+            asm volatile("" ::: "memory");
+        };
+        auto flush = [&]() {                             // BPR.py:58, 64 logs at a time, off the chain
+            if ((unsigned)lane < nsv) nl += -log(chain_sigmoid(xs));
+            nsv = 0;
+        };
+        YUE_CS(unsigned long long cs_work = 0, cs_wait = 0, cs_n = 0; unsigned long long cs_t0 = __builtin_readcyclecounter();)
+        fetch(seq);
+        for (;;) {
+            if (__builtin_expect(!all_lanes(tg == (seq << 2)), 0)) {     // not (yet) the event with this number
+                if (!all_lanes((tg >> 2) == seq)) {                      // not published yet
+                    if (!nap()) break;
+                    fetch(seq);
+                    continue;
+                }
+                idle = 0;
+                const unsigned type = (unsigned)__builtin_amdgcn_readfirstlane((int)tg) & 3u;
+                if (type == kPktExit) break;
+                if (type == kPktStart) {                                 // start of a run: its user row (end of a run: nothing to do here)
 #pragma unroll
-                for (int r = 0; r < KR; ++r) p[r] = d[r];
+                    for (int r = 0; r < KR; ++r) p[r] = d[r];
+                }
+                lds_put(&box.cw[seq & (kTrioRing - 1)][1][lane], seq);   // acknowledged: wave S does not run ahead of this wave
                 ++seq;
+                fetch(seq);
+                YUE_CS(cs_t0 = __builtin_readcyclecounter();)
                 continue;
             }
-            float ai = 0.0f, aj = 0.0f;
+            idle = 0;
+            YUE_CS(const unsigned long long cs_t1 = __builtin_readcyclecounter(); cs_wait += cs_t1 - cs_t0;)
+            const unsigned slot = seq & (kTrioRing - 1);
+            float dd[KR], x;
+            if (FAST) {
+                // within north_star's 1e-5, not bit-equal to the oracle: ONE 64-lane sum of p . (qi - qj), fp32 coefficient
+                float acc = 0.0f;
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { const float mi = p[r] * d[r], mj = p[r] * d[KR + r]; ai = ai + mi; aj = aj + mj; }
-            const float x = wave_sum(ai) - wave_sum(aj);                 // BPR.py:50, fp32 margin
-            const double xd = (double)x;
-            double sg;
-            if (__builtin_fabs(xd) <= 700.0) sg = chain_rcp(1.0 + chain_exp(-xd));     // qmath.py:115-116
-            else sg = 1.0 / (1.0 + exp(-xd));
-            const float c = (float)(a.lr * (1.0 - sg));
-            if (lane == 0) { lds_put(&box.cbits[slot], __builtin_bit_cast(unsigned, c)); asm volatile("" ::: "memory"); lds_put(&box.cseq[slot], seq); }
+                for (int r = 0; r < KR; ++r) { dd[r] = d[r] - d[KR + r]; acc = r == 0 ? p[0] * dd[0] : __builtin_fmaf(p[r], dd[r], acc); }
+                x = wave_sum_any(acc);
+            } else {
+                // per-lane partials in element order 64 r + l, r ascending (oracle/bpr_oracle.c: dot64)
+                float ai = 0.0f, aj = 0.0f;
+#pragma unroll
+                for (int r = 0; r < KR; ++r) { const float mi = p[r] * d[r], mj = p[r] * d[KR + r]; ai = ai + mi; aj = aj + mj; dd[r] = d[r] - d[KR + r]; }
+                x = wave_sum(ai) - wave_sum(aj);                         // BPR.py:50, fp32 margin
+            }
+            fetch(seq + 1u);                                             // the next packet's reads fly under the sigmoid
+            const float c = FAST ? chain_coef_fast(x, lrf) : (float)(a.lr * (1.0 - chain_sigmoid(x)));
+            lds_putf(&box.cw[slot][0][lane], c);
+            asm volatile("" ::: "memory");
+            lds_put(&box.cw[slot][1][lane], seq);
 #pragma unroll
             for (int r = 0; r < KR; ++r) {                               // BPR.py:51, :55 on the user row (as bpr_elem)
-                const float dd = d[r] - d[KR + r];
-                const float td = c * dd;
+                const float td = c * dd[r];
                 const float p1 = p[r] + td;
                 const float rpp = a.ru * p1;
                 p[r] = p1 - rpp;
             }
-            sv = (unsigned)lane == nsv ? sg : sv;
-            if (++nsv == 64u) { nl += -log(sv); nsv = 0; }              // BPR.py:58, 64 logs at a time
+            xs = (unsigned)lane == nsv ? x : xs;
+            if (__builtin_expect(++nsv == 64u, 0)) flush();
             ++seq;
-            YUE_CS(cs_work += __builtin_readcyclecounter() - cs_t1; ++cs_n;)
+            YUE_CS(cs_t0 = __builtin_readcyclecounter(); cs_work += cs_t0 - cs_t1; ++cs_n;)
         }
-        YUE_CS(if (lane == 0) { atomicAdd(a.stats + 0, cs_work); atomicAdd(a.stats + 1, cs_n); atomicAdd(a.stats + 2, cs_wait); atomicAdd(a.stats + 3, cs_n); })
-        if ((unsigned)lane < nsv) nl += -log(sv);
+        YUE_CS(if (lane == 0) { atomicAdd(a.stats + 0, cs_work); atomicAdd(a.stats + 1, cs_n); atomicAdd(a.stats + 2, cs_wait); })
+        flush();
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) nl += __shfl_xor(nl, off);
-        if (lane == 0 && nl != 0.0) atomicAdd(a.nll_slots + ((blockIdx.x * 2 + (wave >> 1)) & (kNllSlots - 1)), nl);
+        if (lane == 0 && nl != 0.0) atomicAdd(a.nll_slots + (blockIdx.x & (kNllSlots - 1)), nl);
         return;
     }
 
-    // -------------------------------------------------------------------- wave M: memory side
-    const unsigned k = (unsigned)a.k;
-    const unsigned row_bytes = (unsigned)GR * 64u * GB;
     unsigned vo[GR];
 #pragma unroll
-    for (int g = 0; g < GR; ++g) vo[g] = (64u * g + lane) * GB;
-    const unsigned v_oob = kOobOffset;
+    for (int g = 0; g < GR; ++g) vo[g] = (64u * g + lane) * GB;      // (elements beyond k are zero-valued granules of the copy: no masking here)
     const uint64_t qbytes = (uint64_t)a.n * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
-    i32x4 rq;
+    i32x4 rq;                                            // buffer descriptor of Qv as plain words, for the assembly operands
     { const uint64_t qa = (uint64_t)a.Qv; rq.x = (int)(uint32_t)qa; rq.y = (int)((uint32_t)(qa >> 32) & 0xffffu); rq.z = qrec; rq.w = kRsrcFlags; }
-    unsigned seq = 1;                                    // next packet number
-    bool dead = false;
-    YUE_CS(unsigned long long cs_mwait = 0, cs_mn = 0;)
+    auto user_rsrc = [&](int64_t u) -> i32x4 {          // user rows as granules: a descriptor based at the row (any number of users)
+        const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * (row_bytes / 4u));
+        i32x4 rp;
+        rp.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)pa); rp.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xffffu));
+        rp.z = (int)row_bytes; rp.w = kRsrcFlags;
+        vmem_sgpr_guard(rp);
+        return rp;
+    };
+
+    if (wave == 2) {
+        // ---------------------------------------------------------------- wave S: item-row updates and all stores
+        float p[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) p[r] = 0.0f;
+        int64_t u_run = 0;
+        uint32_t pver1 = 0u;
+        unsigned seq = 1;
+        YUE_CS(unsigned long long cs_swait = 0, cs_sn = 0;)
+        auto store_user_row = [&]() {
+            if (PVER) {
+                const i32x4 rp = user_rsrc(u_run);
+#pragma unroll
+                for (int q = 0; q < GR; ++q) { if (ONE_XCD) GT::store_l2(GT::make(p[q], pver1), vo[q], rp, 0u); else GT::store(GT::make(p[q], pver1), vo[q], rp, 0u); }
+            } else {
+                float *prow = a.P + (uint64_t)u_run * k;
+#pragma unroll
+                for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; if (e < k) prow[e] = p[q]; }
+            }
+        };
+        // One packet at a time, but never one LDS round trip after the other: the next packet's tag, rows, header and wave C's
+        // answer to it are read while this one is computed.  The hot loop takes events whose answer is there; everything else
+        // (not published yet, no answer yet, start / end / exit packets) is sorted out behind it.
+        unsigned tg, mvn, sq;
+        float dn[2 * KR], cn;
+        auto fetch = [&](unsigned q) {                   // tag before the rows, wave C's sequence number before its coefficient:
+            const unsigned slot = q & (kTrioRing - 1);   // a matching tag / number vouches for what is read behind it
+            tg = lds_get(&box.pkt[slot][TAG][lane]);
+            sq = lds_get(&box.cw[slot][1][lane]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 2 * KR; ++r) dn[r] = lds_getf(&box.pkt[slot][r][lane]);
+            mvn = lds_get(&box.pkt[slot][META][lane]);
+            cn = lds_getf(&box.cw[slot][0][lane]);
+            asm volatile("" ::: "memory");
+        };
+        fetch(seq);
+        for (;;) {
+            for (;;) {
+                unsigned bad = (tg ^ (seq << 2)) | (sq ^ seq);
+                asm volatile("" : "+v"(bad));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) break;
+                // an event and its coefficient
+                lds_put(&box.sdone[lane], seq);          // behind this wave's reads of the slot (LDS order): L may reuse it
+                float d[2 * KR];
+#pragma unroll
+                for (int r = 0; r < 2 * KR; ++r) d[r] = dn[r];
+                const unsigned mv = mvn;
+                const float c = cn;
+                ++seq;
+                fetch(seq);                              // the next packet's reads fly under this one's arithmetic
+                unsigned oi = (unsigned)__builtin_amdgcn_readlane((int)mv, 0) * row_bytes, oj = (unsigned)__builtin_amdgcn_readlane((int)mv, 1) * row_bytes;
+                const uint32_t wi1 = (uint32_t)__builtin_amdgcn_readlane((int)mv, 2) + 1u, wj1 = (uint32_t)__builtin_amdgcn_readlane((int)mv, 3) + 1u;
+                vmem_sgpr_guard(oi, oj);
+#pragma unroll
+                for (int q = 0; q < GR; ++q) {
+                    const Elem o = bpr_elem(p[q], d[q], d[KR + q], c, a.ru, a.ri);    // BPR.py:51-57
+                    p[q] = o.p2;
+                    if (ONE_XCD) { GT::store_l2(GT::make(o.qi2, wi1), vo[q], rq, oi); GT::store_l2(GT::make(o.qj2, wj1), vo[q], rq, oj); }
+                    else {
+                        GT::store(GT::make(o.qi2, wi1), vo[q], rq, oi);            // the positive's row first: the hotter of the two
+                        GT::store(GT::make(o.qj2, wj1), vo[q], rq, oj);
+                    }
+                }
+                YUE_CS(++cs_sn;)
+            }
+            const unsigned type = (unsigned)__builtin_amdgcn_readfirstlane((int)tg) & 3u;
+            const bool here = all_lanes((tg >> 2) == seq);
+            if (here && type == kPktExit) break;
+            if (!here || !all_lanes(sq == seq) || type == kPktEvent) {   // not published yet, or wave C has not answered yet (events: the hot loop's business)
+                if (!nap()) break;
+                fetch(seq);
+                continue;
+            }
+            idle = 0;
+            lds_put(&box.sdone[lane], seq);
+            if (type == kPktStart) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) p[r] = dn[r];
+                u_run = (int64_t)__builtin_amdgcn_readlane((int)mvn, 0);
+                pver1 = (uint32_t)__builtin_amdgcn_readlane((int)mvn, 1);
+            } else if (type == kPktEnd) store_user_row();    // the user row leaves NOW (a later run of the user, any group's, waits for it)
+            ++seq;
+            fetch(seq);
+        }
+        YUE_CS(if (lane == 0) { atomicAdd(a.stats + 5, cs_swait); atomicAdd(a.stats + 6, cs_sn); })
+        return;
+    }
+
+    // -------------------------------------------------------------------- wave L: claims, headers, prefetch ring, version checks
+    unsigned seq = 1, sdone_seen = 0;
+    YUE_CS(unsigned long long cs_lfast = 0, cs_lnfast = 0, cs_lnslow = 0;)
 
     auto all_mine = [&](uint32_t want, const greg (&g)[GR]) -> bool {
-        bool mine = true;
+        unsigned bad = 0u;
 #pragma unroll
-        for (int q = 0; q < GR; ++q) mine = mine && GT::is(g[q], want);
-        return __builtin_amdgcn_ballot_w64(!mine) == 0ull;
+        for (int q = 0; q < GR; ++q) bad |= GT::version(g[q]) ^ want;
+        return all_lanes(bad == 0u);
     };
+    // Slow path of a wait, as in k_bpr_chain: far from its turn a wave sleeps in proportion and polls ONE granule.
     auto acquire_slow = [&](const i32x4 &rs, unsigned so, uint32_t want, greg (&g)[GR]) -> bool {
         uint32_t polls = 0;
         bool fresh = false;
@@ -558,17 +773,28 @@ __global__ void __launch_bounds__(256) k_bpr_chain2(ChainArgs a, const int32_t *
             if (all_mine(want, g)) return true;
         }
     };
-    // a packet to wave C: 2 KR values per lane (or KR for the user row), then the tag
-    auto publish = [&](unsigned type, const float (&v)[2 * KR], int count) {
-        const unsigned slot = seq & (kPairRing - 1);
+    // the slot of packet `seq` is free once wave S is done with packet seq - kTrioRing.  false: gave up
+    auto reserve_slow = [&]() -> bool {
+        for (;;) {
+            sdone_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_get(&box.sdone[lane]));
+            if (seq - sdone_seen <= (unsigned)kTrioRing) { idle = 0; return true; }
+            if (!nap()) return false;
+        }
+    };
+    auto publish = [&](unsigned type, const float (&v)[2 * KR], int count, unsigned mv) {
+        const unsigned slot = seq & (kTrioRing - 1);
 #pragma unroll
-        for (int r = 0; r < 2 * KR; ++r) if (r < count) lds_putf(&box.rows[slot][r][lane], v[r]);
+        for (int r = 0; r < 2 * KR; ++r) if (r < count) lds_putf(&box.pkt[slot][r][lane], v[r]);
+        lds_put(&box.pkt[slot][META][lane], mv);
         asm volatile("" ::: "memory");
-        if (lane == 0) lds_put(&box.tag[slot], (seq << 2) | type);
+        lds_put(&box.pkt[slot][TAG][lane], (seq << 2) | type);
         ++seq;
     };
+    float zeros[2 * KR];
+#pragma unroll
+    for (int r = 0; r < 2 * KR; ++r) zeros[r] = 0.0f;
 
-    while (!dead) {
+    for (;;) {
         unsigned long long run = 0;
         if (lane == 0) run = atomicAdd(a.claim, 1ull);
         run = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(run >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)run);
@@ -578,35 +804,33 @@ __global__ void __launch_bounds__(256) k_bpr_chain2(ChainArgs a, const int32_t *
         const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
         const unsigned len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
 
-        float p[GR];
-        uint32_t pver = 0u;
-        i32x4 rp;
-        if (PVER) {
-            const uint64_t pa = (uint64_t)(a.Pv + (uint64_t)u * (row_bytes / 4u));
-            rp.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)pa); rp.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xffffu));
-            rp.z = (int)row_bytes; rp.w = kRsrcFlags;
-            asm volatile("s_nop 4" : "+s"(rp));                       // VALU-written SGPRs, vector memory in assembly: see k_bpr_chain
-            pver = a.ord_u[run];
-            greg g[GR];
-#pragma unroll
-            for (int q = 0; q < GR; ++q) GT::load(g[q], vo[q], rp, 0u);
-            row_wait_all<GR>(g);
-            if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) { dead = true; break; }
-#pragma unroll
-            for (int q = 0; q < GR; ++q) p[q] = GT::value(g[q]);
-        } else {
-            const float *prow = a.P + (uint64_t)u * k;
-#pragma unroll
-            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; p[q] = e < k ? prow[e] : 0.0f; }
-        }
-        {   // the user row to wave C
+        {   // the user row to waves C and S
             float v[2 * KR];
+            uint32_t pver = 0u;
 #pragma unroll
-            for (int r = 0; r < KR; ++r) { v[r] = p[r]; v[KR + r] = 0.0f; }
-            publish(kPktStart, v, KR);
+            for (int r = 0; r < 2 * KR; ++r) v[r] = 0.0f;
+            if (PVER) {
+                const i32x4 rp = user_rsrc(u);
+                pver = a.ord_u[run];
+                greg g[GR];
+#pragma unroll
+                for (int q = 0; q < GR; ++q) GT::load(g[q], vo[q], rp, 0u);
+                row_wait_all<GR>(g);
+                if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) goto bail;
+#pragma unroll
+                for (int q = 0; q < GR; ++q) v[q] = GT::value(g[q]);
+            } else {
+                const float *prow = a.P + (uint64_t)u * k;
+#pragma unroll
+                for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; v[q] = e < k ? prow[e] : 0.0f; }
+            }
+            unsigned mv = pver + 1u;                                     // lane 0: the user, lane 1: the version the row leaves with
+            mv = write_lane<0>(mv, (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
+            if (seq - sdone_seen > (unsigned)kTrioRing && !reserve_slow()) goto bail;
+            publish(kPktStart, v, KR, mv);
         }
 
-        for (unsigned seg = 0; seg < len && !dead; seg += 64u) {
+        for (unsigned seg = 0; seg < len; seg += 64u) {
             int hAi, hAj;
             uint32_t hAwi, hAwj;
             {
@@ -616,130 +840,72 @@ __global__ void __launch_bounds__(256) k_bpr_chain2(ChainArgs a, const int32_t *
                 if (!ex) { hAi = 0; hAj = -1; }
             }
             greg gi[G][GR], gj[G][GR];
+            // loads of one slot: always 2 GR ring loads; a slot without an event (a skipped triplet, the lanes past the run's end,
+            // the last group's refills) loads row 0 instead -- never looked at, it only keeps the count of the waits exact
             auto fill = [&](int s, int i_, int j_) {
-                const bool live = j_ >= 0;
-                const unsigned oi = live ? (unsigned)i_ * row_bytes : 0u, oj = live ? (unsigned)j_ * row_bytes : 0u;
+                unsigned oi = (unsigned)i_ * row_bytes, oj = (unsigned)(j_ < 0 ? 0 : j_) * row_bytes;
+                vmem_sgpr_guard(oi, oj);
 #pragma unroll
-                for (int q = 0; q < GR; ++q) {
-                    const unsigned v = live ? vo[q] : v_oob;
-                    GT::load(gj[s][q], v, rq, oj); GT::load(gi[s][q], v, rq, oi);
-                }
+                for (int q = 0; q < GR; ++q) { GT::load(gj[s][q], vo[q], rq, oj); GT::load(gi[s][q], vo[q], rq, oi); }
             };
-#pragma unroll
-            for (int q = 0; q < GR; ++q) asm volatile("" : "+v"(p[q]));
+            // (the compiler's own loads above are waited for HERE, not in front of a step, where the wait would drain the ring)
             asm volatile("" : "+v"(hAi), "+v"(hAj), "+v"(hAwi), "+v"(hAwj));
 #pragma unroll
             for (int s = 0; s < G; ++s) fill(s, __builtin_amdgcn_readlane(hAi, s), __builtin_amdgcn_readlane(hAj, s));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring is full: from here on the counted waits hold
 
             const unsigned seg_len = len - seg < 64u ? len - seg : 64u;
-            // Counted waits as in k_bpr_chain: every step issues 2 GR stores and 2 GR loads; a slot's loads have at least
-            // (G - 2) whole steps behind them when the step BEFORE its own looks ahead at it.
-            // Step t: [rows of triplet t + 1: wait, check, publish (postponed if a row still waits for MY store of triplet t)]
-            // [coefficient of t from wave C] [update and store t] [postponed publish] [refill slot t with triplet t + G].
-            // Published-but-unanswered triplets: at most two, the ring of kPairRing slots never wraps onto them.
-            bool have = false;                                       // rows of the current triplet are published
-            unsigned cur_seq = 0;
-            // try to publish the rows of slot s (already waited for); false: a row does not carry its ordinal yet
-            auto try_publish = [&](int s, uint32_t wi, uint32_t wj) -> bool {
-                if (!all_mine(wj, gj[s]) || !all_mine(wi, gi[s])) return false;
-                float v[2 * KR];
-#pragma unroll
-                for (int q = 0; q < GR; ++q) { v[q] = GT::value(gi[s][q]); v[KR + q] = GT::value(gj[s][q]); }
-                publish(kPktEvent, v, 2 * KR);
-                return true;
-            };
-            for (unsigned ol = 0; ol < seg_len && !dead; ol += G) {
-                const bool more = ol + G < 64u;
+            // this wave issues loads only: every step exactly 2 GR of them, so a slot's loads have (G - 1) * 2 GR younger ones
+            // behind them when its turn comes (refills stay inside the segment of 64: the last group's reload the group itself)
+            for (unsigned ol = 0; ol < seg_len; ol += G) {
+                const unsigned nxt = ol + G < 64u ? ol + G : ol;
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
-                    const int ti = __builtin_amdgcn_readlane(hAi, ol + s), tj = __builtin_amdgcn_readlane(hAj, ol + s);
-                    const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, ol + s), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, ol + s);
-                    const unsigned oi = (unsigned)(ti < 0 ? 0 : ti) * row_bytes, oj = (unsigned)(tj < 0 ? 0 : tj) * row_bytes;
-                    const bool live = tj >= 0 && !dead;
-                    // the NEXT live triplet's slot and header (inside this group: slot s + 1; the first slot of the next group
-                    // is handled at that group's first step, after its own wait)
-                    if (live && !have) {                             // first triplet of a group / after a gap: publish it now
-                        ring_wait<GR, (G - 2) * 4 * GR>(gi[s], gj[s]);
-                        bool ok = try_publish(s, wi, wj);
-                        if (!ok) {
-                            ok = (all_mine(wj, gj[s]) || acquire_slow(rq, oj, wj, gj[s])) && (all_mine(wi, gi[s]) || acquire_slow(rq, oi, wi, gi[s]));
-                            if (ok) ok = try_publish(s, wi, wj);
-                        }
-                        if (!ok) dead = true;
-                        cur_seq = seq - 1u;
-                        have = ok;
-                    }
-                    bool done = false;
-                    if (live && !dead) {
-                        // look ahead: rows of the next triplet of this group
-                        bool next_pub = false, next_live = false;
-                        int nti = 0, ntj = -1; uint32_t nwi = 0u, nwj = 0u;
-                        if (s + 1 < G) {
-                            nti = __builtin_amdgcn_readlane(hAi, (ol + s + 1) & 63u); ntj = (ol + s + 1 < 64u) ? __builtin_amdgcn_readlane(hAj, (ol + s + 1) & 63u) : -1;
-                            nwi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, (ol + s + 1) & 63u); nwj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, (ol + s + 1) & 63u);
-                            next_live = ntj >= 0;
-                            if (next_live) {
-                                ring_wait<GR, (G - 2) * 4 * GR>(gi[(s + 1) % G], gj[(s + 1) % G]);
-                                next_pub = try_publish((s + 1) % G, nwi, nwj);
-                            }
-                        }
-                        // the coefficient of this triplet
-                        const unsigned cslot = cur_seq & (kPairRing - 1);
-                        YUE_CS(const unsigned long long cs_m0 = __builtin_readcyclecounter();)
-                        while (lds_get(&box.cseq[cslot]) != cur_seq) __builtin_amdgcn_s_sleep(1);
-                        asm volatile("" ::: "memory");
-                        YUE_CS(cs_mwait += __builtin_readcyclecounter() - cs_m0; ++cs_mn;)
-                        const float c = __builtin_bit_cast(float, lds_get(&box.cbits[cslot]));
+                    YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter(); bool cs_waited = false;)
+                    ring_wait<GR, (G - 1) * 2 * GR>(gi[s], gj[s]);
+                    const int tj = __builtin_amdgcn_readlane(hAj, ol + s);
+                    if (tj >= 0) {                                   // (wave-uniform) an event of the run with a negative
+                        const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, ol + s), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, ol + s);
+                        const int ti = __builtin_amdgcn_readlane(hAi, ol + s);
+                        // all granules carry their ordinals and the ring of packets has room: ONE test (xor / or in the vector ALU;
+                        // the empty statement keeps the compiler from turning it back into one compare and branch per granule)
+                        unsigned bad = seq - sdone_seen > (unsigned)kTrioRing ? 1u : 0u;
 #pragma unroll
-                        for (int q = 0; q < GR; ++q) {
-                            const float qi = GT::value(gi[s][q]), qj = GT::value(gj[s][q]);
-                            const Elem o = bpr_elem(p[q], qi, qj, c, a.ru, a.ri);
-                            p[q] = o.p2;
-                            GT::store(GT::make(o.qi2, wi + 1u), vo[q], rq, oi);
-                            GT::store(GT::make(o.qj2, wj + 1u), vo[q], rq, oj);
+                        for (int q = 0; q < GR; ++q) bad |= (GT::version(gi[s][q]) ^ wi) | (GT::version(gj[s][q]) ^ wj);
+                        asm volatile("" : "+v"(bad));
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {
+                            // a row does not carry its ordinal yet, or the ring of packets is full
+                            unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)tj * row_bytes;
+                            vmem_sgpr_guard(oi, oj);
+                            if (!all_mine(wj, gj[s]) && !acquire_slow(rq, oj, wj, gj[s])) goto bail;
+                            if (!all_mine(wi, gi[s]) && !acquire_slow(rq, oi, wi, gi[s])) goto bail;
+                            if (seq - sdone_seen > (unsigned)kTrioRing && !reserve_slow()) goto bail;
+                            YUE_CS(cs_waited = true;)
                         }
-                        done = true;
-                        have = false;
-                        if (next_live) {
-                            if (!next_pub) {                         // its row waited for the stores just issued (or for another wave)
-                                const unsigned noi = (unsigned)nti * row_bytes, noj = (unsigned)ntj * row_bytes;
-                                bool ok = (all_mine(nwj, gj[(s + 1) % G]) || acquire_slow(rq, noj, nwj, gj[(s + 1) % G])) &&
-                                          (all_mine(nwi, gi[(s + 1) % G]) || acquire_slow(rq, noi, nwi, gi[(s + 1) % G]));
-                                if (ok) ok = try_publish((s + 1) % G, nwi, nwj);
-                                if (!ok) dead = true;
-                            }
-                            cur_seq = seq - 1u;
-                            have = !dead;
-                        }
-                    }
-                    if (!done) {
-                        greg z = GT::make(0.0f, 0u);
+                        float v[2 * KR];
 #pragma unroll
-                        for (int q = 0; q < GR; ++q) { GT::store(z, v_oob, rq, 0u); GT::store(z, v_oob, rq, 0u); }
+                        for (int q = 0; q < GR; ++q) { v[q] = GT::value(gi[s][q]); v[KR + q] = GT::value(gj[s][q]); }
+                        unsigned mv = wj;                            // lanes 0..3: the two items, the two ordinals (wave S adds the rest)
+                        mv = write_lane<0>(mv, (unsigned)ti);
+                        mv = write_lane<1>(mv, (unsigned)tj);
+                        mv = write_lane<2>(mv, wi);
+                        publish(kPktEvent, v, 2 * KR, mv);
                     }
-                    fill(s, more ? __builtin_amdgcn_readlane(hAi, (ol + G + s) & 63u) : 0, more ? __builtin_amdgcn_readlane(hAj, (ol + G + s) & 63u) : -1);
+                    // refill with the same slot of the next group
+                    fill(s, __builtin_amdgcn_readlane(hAi, nxt + s), __builtin_amdgcn_readlane(hAj, nxt + s));
+                    YUE_CS(if (tj >= 0) { if (cs_waited) ++cs_lnslow; else { cs_lfast += __builtin_readcyclecounter() - cs_t0; ++cs_lnfast; } })
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing of this segment's ring is in flight when the next one refills it
         }
-        if (dead) break;
-        if (PVER) {
-#pragma unroll
-            for (int q = 0; q < GR; ++q) GT::store(GT::make(p[q], pver + 1u), vo[q], rp, 0u);
-        } else {
-            float *prow = a.P + (uint64_t)u * k;
-#pragma unroll
-            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; if (e < k) prow[e] = p[q]; }
-        }
+        // end of the run: wave S stores the user row
+        if (seq - sdone_seen > (unsigned)kTrioRing && !reserve_slow()) goto bail;
+        publish(kPktEnd, zeros, 0, 0u);
     }
-    YUE_CS(if (lane == 0) { atomicAdd(a.stats + 4, cs_mwait); atomicAdd(a.stats + 5, cs_mn); })
-    {   // wave C leaves
-        float v[2 * KR];
-#pragma unroll
-        for (int r = 0; r < 2 * KR; ++r) v[r] = 0.0f;
-        publish(kPktExit, v, 0);
-    }
+bail:
+    YUE_CS(if (lane == 0) { atomicAdd(a.stats + 3, cs_lfast); atomicAdd(a.stats + 4, cs_lnfast); atomicAdd(a.stats + 7, cs_lnslow); })
+    // the other two waves leave (a full ring drains first; when this wave gave up, the status word ends their waits)
+    if (seq - sdone_seen <= (unsigned)kTrioRing || reserve_slow()) publish(kPktExit, zeros, 0, 0u);
 }
 
 }  // namespace yue

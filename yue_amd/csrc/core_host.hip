@@ -52,6 +52,8 @@ int yue_ctx_destroy(yue_ctx *c) {
     if (c->ev_t_rounds) (void)hipEventDestroy(c->ev_t_rounds);
     if (c->ev_t_comm) (void)hipEventDestroy(c->ev_t_comm);
     if (c->ev_scan0) (void)hipEventDestroy(c->ev_scan0);
+    if (c->ev_chain0) (void)hipEventDestroy(c->ev_chain0);
+    if (c->ev_chain1) (void)hipEventDestroy(c->ev_chain1);
     if (c->ev_scan1) (void)hipEventDestroy(c->ev_scan1);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();

@@ -139,10 +139,14 @@ struct yue_ctx {
     bool d_ev_ptr_valid = false;
     int opt_epoch_exact = 0;             // 1: yue_bpr_epoch applies the epoch's triplets with exact sequential semantics (k_bpr_chain)
     int opt_replay_levels = 0;           // 1: yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path)
-    int opt_chain_split = 0;             // 1: a run is walked by a pair of waves (k_bpr_chain2: memory side / dependency chain)
+    int opt_chain_split = 0;             // 1: a run is walked by three waves (k_bpr_chain3: loads / dependency chain / stores)
+    int opt_chain_ring = 0;              // three-wave kernel: triplets whose rows the loading wave keeps in flight (0 = 8; 16 for k <= 128)
+    int opt_chain_xcd = 0;               // three-wave kernel: 1 = all working waves on ONE XCD, rows handed over through its L2
+    int opt_chain_fast = 0;              // 1: single-precision coefficient, one 64-lane sum per triplet (within 1e-5, not bit-equal)
     int opt_chain_waves = 0;             // workgroups per CU of the persistent launch (0: what fits, at most 8)
     int64_t opt_chain_spin = 0;          // polls per wait before a wave gives up (0: 2^22)
-    int64_t chain_runs = 0, chain_waves = 0, replay_levels = 0;
+    int64_t chain_runs = 0, chain_waves = 0, chain_groups = 0, chain_kernel_us = 0, replay_levels = 0;
+    hipEvent_t ev_chain0 = nullptr, ev_chain1 = nullptr;   // brackets of the dataflow launch (read-only option chain_last_us)
     // RCCL
     ncclComm *comm = nullptr;              // ncclComm_t (comm.hip)
     int rank = 0, nranks = 1;
