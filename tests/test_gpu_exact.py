@@ -143,7 +143,7 @@ def _exact_epoch(dev, data, P0, Q0, seed, split, fast, epochs=1, xcd=0):
         nll = [dev.bpr_epoch(seed, ep, 0, 0.02, 0.01, 0.01)[0] for ep in range(epochs)]
     finally:
         dev.set_option('epoch_exact', 0)
-        dev.set_option('chain_split', 0)
+        dev.set_option('chain_split', -1)
         dev.set_option('chain_fast', 0)
         dev.set_option('chain_xcd', 0)
     return (nll,) + dev.get_factors()
@@ -186,7 +186,7 @@ def test_three_wave_replay_of_an_interleaved_stream_is_bit_equal(dev):
         try:
             nll = dev.bpr_replay(u, i, j, 0.03, 0.02, 0.01)
         finally:
-            dev.set_option('chain_split', 0)
+            dev.set_option('chain_split', -1)
             dev.set_option('chain_xcd', 0)
         res.append((nll,) + dev.get_factors())
     for other in res[1:]:

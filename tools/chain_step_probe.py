@@ -30,7 +30,7 @@ def timed_replay(dev, P0, Q0, u, i, j):
 
 def main():
     k = 128
-    R, POOL = 256, 4096                                # a run re-visits an item of its private pool 2,048 triplets later
+    R, POOL = 256, int(os.environ.get('PROBE_POOL', '4096'))    # a run re-visits an item of its private pool POOL / 2 triplets later (>= 64: beyond the prefetch ring)
     n = R * POOL + 400000
     m = 300000
     P0, Q0 = synth.init_factors(m, n, k, 3)
@@ -48,7 +48,10 @@ def main():
         j = (base + (2 * t + 1) % POOL).astype(np.int32)
         res[L] = timed_replay(dev, P0, Q0, u, i, j)
     step = (res[20000] - res[4000]) / 16000
-    print('in-run step: %.3f us (dataflow launch alone)  (%d runs; %d triplets per run: %.1f ms, %d: %.1f ms)' % (1e6 * step, R, 4000, 1e3 * res[4000], 20000, 1e3 * res[20000]), flush=True)
+    print('pool %d: in-run step: %.3f us (dataflow launch alone)  (%d runs; %d triplets per run: %.1f ms, %d: %.1f ms)' % (POOL, 1e6 * step, R, 4000, 1e3 * res[4000], 20000, 1e3 * res[20000]), flush=True)
+    if os.environ.get('PROBE_STEP_ONLY'):
+        dev.close()
+        return
     for H in (100000, 300000):
         u = np.arange(H, dtype=np.int32)
         i = np.zeros(H, np.int32) + (n - 1)

@@ -3,7 +3,7 @@ set -o pipefail
 O=gpurun_out/${1:-r4f}; mkdir -p $O
 timeout -k 10 900 python -m pytest tests/test_gpu_exact.py -x -q -m gpu -s > $O/exact_tests.log 2>&1 || { tail -30 $O/exact_tests.log; exit 1; }
 tail -3 $O/exact_tests.log
-for opts in "chain_split=1 chain_fast=0" "chain_split=1 chain_fast=1" "chain_split=1 chain_fast=1 chain_ring=16" "chain_split=1 chain_fast=0 chain_xcd=1" "chain_split=1 chain_fast=1 chain_xcd=1"; do
+for opts in "chain_split=1 chain_fast=0" "chain_split=1 chain_fast=1" "chain_split=1 chain_fast=0 chain_xcd=1" "chain_split=1 chain_fast=1 chain_xcd=1"; do
   tag=$(echo $opts | tr ' =' '__')
   timeout -k 10 300 python tools/chain_step_probe.py $opts > $O/step_$tag.log 2>&1 || { tail -20 $O/step_$tag.log; exit 1; }
   echo "== $opts"; cat $O/step_$tag.log

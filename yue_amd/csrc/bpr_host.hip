@@ -792,7 +792,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
     if (key == "epoch_exact") { c->opt_epoch_exact = value != 0; return YUE_OK; }
     if (key == "replay_levels") { c->opt_replay_levels = value != 0; return YUE_OK; }
-    if (key == "chain_split") { c->opt_chain_split = value != 0; return YUE_OK; }
+    if (key == "chain_split") { if (value < -1 || value > 1) return fail(YUE_ERR_ARG, "yue_set_option: chain_split must be -1, 0 or 1"); c->opt_chain_split = (int)value; return YUE_OK; }
     if (key == "chain_fast") { c->opt_chain_fast = value != 0; return YUE_OK; }
     if (key == "chain_xcd") { c->opt_chain_xcd = value != 0; return YUE_OK; }
     if (key == "chain_ring") { if (value != 0 && value != 8 && value != 16) return fail(YUE_ERR_ARG, "yue_set_option: chain_ring must be 0, 8 or 16"); c->opt_chain_ring = (int)value; return YUE_OK; }

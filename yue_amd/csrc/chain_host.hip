@@ -80,8 +80,9 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     // longest chain of dependent triplets times the latency of a step, and a wave alone on its SIMD has the shortest step
     // (measured on BASELINE config 3 with k_bpr_chain: 913 ms per epoch with 1,024 waves, 1,131 ms with 3,072), so the default
     // is ONE workgroup per CU (option chain_waves = workgroups per CU):
-    //   chain_split = 1 (default): k_bpr_chain3, a workgroup = three waves (loads / chain / stores) walking one run;
-    //   chain_split = 0: k_bpr_chain, a workgroup = four waves, each walking a run of its own.
+    //   chain_split = 1: k_bpr_chain3, a workgroup = five waves (2 x loads / chain / 2 x stores) walking one run;
+    //   chain_split = 0: k_bpr_chain, a workgroup = four waves, each walking a run of its own;
+    //   chain_split = -1 (default): the first for streams of at least 16 triplets per run.
     // chain_fast = 1: single-precision coefficient and one 64-lane sum per triplet (within 1e-5 of the reference, not bit-equal).
     int per_cu = 0, cus = 0;
     const int kr = kr_of(k);
@@ -89,6 +90,9 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     int waves_per_block = 4;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     bool one_xcd = false, allow_one_xcd = true;
+    // which kernel: the wave group shortens the step of a run (config 3: 940 -> 607 ms per epoch, bit-equal) but makes the
+    // start of a run and every cross-wave hand-off dearer (one rank's share of config 4, 6 triplets per run: 181 -> 291 ms)
+    const bool split = c->opt_chain_split < 0 ? T >= 16 * R : c->opt_chain_split != 0;
     auto launch = [&](auto kernel, int threads, int64_t runs_per_block) -> int {
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
         per_cu = std::max(1, std::min(per_cu, c->opt_chain_waves > 0 ? c->opt_chain_waves : (one_xcd ? 2 : 1)));
@@ -103,11 +107,11 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     if (!c->ev_chain0) { HIPCHK(hipEventCreate(&c->ev_chain0)); HIPCHK(hipEventCreate(&c->ev_chain1)); }
     a.xcd = 0u; a.groups = c->ch_ctl.p + 3;
     // ring of 8 prefetched triplets per wave (k_bpr_chain at k > 128: 4, register budget)
-#define YUE_CHAIN3(KR_, PV_, G_, X_) (c->opt_chain_fast ? launch(yue::k_bpr_chain3<KR_, PV_, G_, true, X_>, 192, 1) : launch(yue::k_bpr_chain3<KR_, PV_, G_, false, X_>, 192, 1))
+#define YUE_CHAIN3(KR_, PV_, G_, X_) (c->opt_chain_fast ? launch(yue::k_bpr_chain3<KR_, PV_, G_, true, X_>, 320, 1) : launch(yue::k_bpr_chain3<KR_, PV_, G_, false, X_>, 320, 1))
 #define YUE_CHAIN_RUN(KR_, PV_, G1_)                                                                                    \
     do {                                                                                                                  \
-        if (c->opt_chain_split) {                                                                                         \
-            waves_per_block = 3;                                                                                          \
+        if (split) {                                                                                                      \
+            waves_per_block = 5;                                                                                          \
             one_xcd = c->opt_chain_xcd != 0 && allow_one_xcd;                                                                           \
             if (c->opt_chain_ring == 16 && KR_ <= 2) rc = one_xcd ? YUE_CHAIN3(KR_, PV_, (KR_ <= 2 ? 16 : 8), true) : YUE_CHAIN3(KR_, PV_, (KR_ <= 2 ? 16 : 8), false); \
             else rc = one_xcd ? YUE_CHAIN3(KR_, PV_, 8, true) : YUE_CHAIN3(KR_, PV_, 8, false);                           \
@@ -144,9 +148,9 @@ int chain_launch(yue_ctx *c, const int32_t *ev_u, const int32_t *ev_i, const int
     {
         unsigned long long h[8];
         HIPCHK(hipMemcpy(h, c->ch_stats.p, sizeof h, hipMemcpyDeviceToHost));
-        if (c->opt_chain_split)
-            fprintf(stderr, "[chain3 stats] wave C: %.0f cycles of work per triplet, %.0f waiting for its rows (%llu triplets); wave L: %.0f cycles per step without a wait (%llu steps, %llu more waited for a row); wave S: %.0f cycles from a packet to its coefficient\n",
-                    h[1] ? (double)h[0] / h[1] : 0.0, h[1] ? (double)h[2] / h[1] : 0.0, h[1], h[4] ? (double)h[3] / h[4] : 0.0, h[4], h[7], h[6] ? (double)h[5] / h[6] : 0.0);
+        if (split)
+            fprintf(stderr, "[chain3 stats] per triplet: wave C %.0f cycles of work + %.0f waiting for a packet; wave L %.0f cycles per step without a wait (%llu steps) and %.0f waiting for room in the ring; wave S %.0f cycles waiting for packets or answers (%llu triplets)\n",
+                    h[1] ? (double)h[0] / h[1] : 0.0, h[1] ? (double)h[2] / h[1] : 0.0, h[4] ? (double)h[3] / h[4] : 0.0, h[4], h[1] ? (double)h[7] / h[1] : 0.0, h[6] ? (double)h[5] / h[6] : 0.0, h[6]);
         else
         fprintf(stderr, "[chain stats] steps without a wait: %llu, %.0f cycles each; steps that waited: %llu (%.2f %%), %.0f cycles each; per run outside the steps: %.0f cycles (%llu runs)\n",
                 h[1], h[1] ? (double)h[0] / h[1] : 0.0, h[3], 100.0 * h[3] / (double)(h[1] + h[3] + 1e-9), h[3] ? (double)h[2] / h[3] : 0.0, h[5] ? (double)h[4] / h[5] : 0.0, h[5]);

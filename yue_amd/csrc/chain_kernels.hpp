@@ -24,6 +24,8 @@
 #pragma once
 #include "bpr_device.hpp"
 
+#include <type_traits>
+
 namespace yue {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -56,6 +58,13 @@ struct ChainArgs {
                                  // [2] cycles in steps that waited, [3] such steps, [4] cycles per run outside the steps, [5] runs
 #endif
 };
+// timing-only ablations of k_bpr_chain3 (make EXTRA=-DYUE_ABL=bits OBJDIR=build_ablN LIB=libyue_hip_ablN.so; results WRONG by
+// construction, never loaded by the package): 1 no version check in wave L, 2 no row writes to LDS, 4 no header words, 8 no
+// refill loads, 16 no granule stores in wave S (implied by 4), 32 no arithmetic in wave S, 64 wave L's per-step headers from the
+// packet number instead of v_readlane
+#ifndef YUE_ABL
+#define YUE_ABL 0
+#endif
 #ifdef YUE_CHAIN_STATS
 #define YUE_CS(...) __VA_ARGS__
 #else
@@ -457,35 +466,38 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The same dataflow with the work of a run split over THREE waves of one workgroup (one wave per SIMD of a CU).  A lone wave
-// issues its instructions one after the other, so the latency of a step of k_bpr_chain is the number of its instructions
-// (~250), of which the next triplet of the run needs only the margin, the sigmoid and the new user row.  Here
-//   wave L ("loads"):  claims runs, keeps the headers, the ring of prefetched granule rows with its counted waits, the version
-//       checks and the polling; a row pair that carries its ordinals is PUBLISHED to the other two waves through LDS;
-//   wave C ("chain"):  reads published rows from LDS, computes the margin, the sigmoid and c = fp32(lr (1 - s)), hands c on
+// The same dataflow with the work of a run split over the waves of one workgroup (a CU's four SIMDs).  A lone wave issues its
+// instructions one after the other, so the latency of a step of k_bpr_chain is the number of its instructions (~250), of which
+// the next triplet of the run needs only the margin, the sigmoid and the new user row.  Here
+//   wave C ("chain"):   reads published rows from LDS, computes the margin, the sigmoid and c = fp32(lr (1 - s)), hands c on
 //       through LDS, updates its copy of the user row, keeps the loss.  No global memory, no headers, no version checks: the
 //       dependency chain of a run and nothing else;
-//   wave S ("stores"): takes the published rows and c, applies the reference's update to the two item rows (and to its own
-//       copy of the user row: same instructions as wave C, same values), stores the granules with version + 1, and the
-//       user row as soon as the run's end packet arrives.
-// (Round 3's two-wave split left the memory side as long as the chain side: no gain.  With the memory side split in two
-// the chain wave alone sets the step.)
-// Packets L -> C, S carry a sequence number that grows over the whole launch (slot = number mod kTrioRing): a stale slot
-// never matches.  Every word of the LDS mailboxes exists once per lane (lane l reads and writes word l): no exec masking, no
-// broadcast; LDS serves a wave's operations in order, so "rows, then tag" written by L and "tag, then rows" read by C and S
-// need no fence, and a wave that has been answered (coefficient from C, progress word from S) knows the other side's reads
-// of the slot are done.
+//   waves L0, L1 ("loads"): claim runs (L0; L1 follows through a mailbox), keep the headers, a ring of prefetched granule rows
+//       each with its counted waits, the version checks and the polling; L0 takes the even triplets of a segment, L1 the odd
+//       ones; a row pair that carries its ordinals is PUBLISHED to the other waves through LDS under the triplet's packet
+//       number (start packet of the run + live triplets before it: both waves count the same way);
+//   waves Si, Sj ("stores"): take the published rows and c, apply the reference's update to the positive's (Si) or the
+//       negative's (Sj) row and to their own copy of the user row (same instructions as wave C, same values), store the
+//       granules with version + 1; Si stores the user row as soon as the run's end packet arrives.
+// (Round 3's two-wave split left the memory side as long as the chain side: no gain.  Measured per triplet on one wave alone:
+// chain 265 cycles with the short coefficient (600 in double precision), loads 490, stores 370 -- hence two of each.)
+// Packets carry a sequence number that grows over the whole launch (slot = number mod kTrioRing): a stale slot never matches.
+// Every word of the LDS mailboxes exists once per lane (lane l reads and writes word l): no exec masking, no broadcast; LDS
+// serves a wave's operations in order, so "rows, then tag" written by L and "tag, then rows" read by C and S need no fence, and
+// a wave that has been answered (coefficient from C, progress words from S) knows the other side's reads of the slot are done.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kTrioRing = 16;
 constexpr unsigned kPktEvent = 0u, kPktStart = 1u, kPktExit = 2u, kPktEnd = 3u;
 
 template <int KR>
 struct TrioBox {
-    static constexpr int ROWS = KR == 2 ? 8 : 2 * KR + 2;               // (k <= 128: a slot of 2 KB, its address is a shift)
-    static constexpr int META = 2 * KR, TAG = 2 * KR + 1;
-    float pkt[kTrioRing][ROWS][64];        // event: qi[0..KR), qj[KR..2KR); start: the user row in [0..KR); then meta, tag
-    unsigned cw[kTrioRing][2][64];         // from wave C: [0] coefficient of the slot's triplet, [1] sequence number it answers
-    unsigned sdone[64];                    // from wave S: last packet it is done with (L may reuse the slot kTrioRing later)
+    // Every record is 8 bytes per lane, written and read as ONE 64-bit LDS operation per lane (half the LDS instructions of
+    // single words, and a record's two halves always belong together):
+    unsigned long long rows[kTrioRing][KR][64];   // the 2 KR values of a packet in pairs: event qi[0..KR), qj[0..KR); start: the user row first
+    unsigned long long hdr[kTrioRing][64];        // {header word (low), tag (high)} -- written after the rows, read before them
+    unsigned long long cw[kTrioRing][64];         // from wave C: {coefficient of the slot's triplet (low), sequence number it answers (high)}
+    unsigned sdone[2][64];                 // from the two S waves: last packet each is done with (a slot is reused kTrioRing packets later)
+    unsigned runbox[kTrioRing][64];        // from wave L0 to wave L1: the runs it has claimed (lanes 0..4: first event lo / hi, length, number of the start packet, run counter)
 };
 static_assert(sizeof(TrioBox<4>) <= 64 * 1024, "static LDS");
 
@@ -493,12 +505,16 @@ static_assert(sizeof(TrioBox<4>) <= 64 * 1024, "static LDS");
 // merged by the compiler, no waits on the vector-memory queue) between compiler barriers; the LDS keeps a wave's operations in order.
 __device__ __forceinline__ unsigned lds_get(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_put(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ unsigned lds_get(const float *p) { return lds_get(reinterpret_cast<const unsigned *>(p)); }
-__device__ __forceinline__ void lds_put(float *p, unsigned v) { lds_put(reinterpret_cast<unsigned *>(p), v); }
-__device__ __forceinline__ float lds_getf(const float *p) { return __builtin_bit_cast(float, lds_get(p)); }
-__device__ __forceinline__ float lds_getf(const unsigned *p) { return __builtin_bit_cast(float, lds_get(p)); }
-__device__ __forceinline__ void lds_putf(float *p, float v) { lds_put(p, __builtin_bit_cast(unsigned, v)); }
-__device__ __forceinline__ void lds_putf(unsigned *p, float v) { lds_put(p, __builtin_bit_cast(unsigned, v)); }
+struct Pair { unsigned lo, hi; };
+__device__ __forceinline__ Pair lds_get2(const unsigned long long *p) {
+    const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    Pair r; r.lo = (unsigned)v; r.hi = (unsigned)(v >> 32); return r;
+}
+__device__ __forceinline__ void lds_put2(unsigned long long *p, unsigned lo, unsigned hi) {
+    __hip_atomic_store(p, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float bitsf(unsigned v) { return __builtin_bit_cast(float, v); }
 __device__ __forceinline__ bool all_lanes(bool b) { return __builtin_amdgcn_ballot_w64(!b) == 0ull; }
 // v with lane L replaced by the wave-uniform s (v_writelane_b32; this compiler has no builtin for it)
 template <int L> __device__ __forceinline__ unsigned write_lane(unsigned v, unsigned s) { asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L)); return v; }
@@ -511,13 +527,12 @@ template <int L> __device__ __forceinline__ unsigned write_lane(unsigned v, unsi
 // leaves at once unless it is the chosen one (workgroups are dealt round-robin over the XCDs; nothing depends on that being
 // exact: whoever stays works, the host checks that somebody did).
 template <int KR, bool PVER, int G, bool FAST, bool ONE_XCD>
-__global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
+__global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                     const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
     constexpr int GR = KR, GB = 8;
     typedef Gran GT;
     typedef typename GT::reg greg;
     typedef TrioBox<KR> Box;
-    constexpr int TAG = Box::TAG, META = Box::META;
     __shared__ Box box;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -527,8 +542,8 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
         if ((xcc & 15u) != a.xcd) return;                // (the whole workgroup: it sits on one XCD)
         if (threadIdx.x == 0) atomicAdd(a.groups, 1ull);
     }
-    for (int t = threadIdx.x; t < kTrioRing * 64; t += 192) { box.pkt[t >> 6][TAG][t & 63] = 0.0f; box.cw[t >> 6][1][t & 63] = 0u; }
-    if (threadIdx.x < 64) box.sdone[threadIdx.x] = 0u;
+    for (int t = threadIdx.x; t < kTrioRing * 64; t += 320) { box.hdr[t >> 6][t & 63] = 0ull; box.cw[t >> 6][t & 63] = 0ull; box.runbox[t >> 6][t & 63] = 0u; }
+    if (threadIdx.x < 128) box.sdone[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
     __syncthreads();
     const unsigned k = (unsigned)a.k;
     const unsigned row_bytes = (unsigned)GR * 64u * GB;  // granule rows
@@ -558,10 +573,10 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
         const float lrf = (float)a.lr;
         auto fetch = [&](unsigned q) {                   // tag first, then the rows: a matching tag vouches for the rows read behind it
             const unsigned slot = q & (kTrioRing - 1);
-            tg = lds_get(&box.pkt[slot][TAG][lane]);
+            tg = lds_get2(&box.hdr[slot][lane]).hi;
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 2 * KR; ++r) d[r] = lds_getf(&box.pkt[slot][r][lane]);
+            for (int w = 0; w < KR; ++w) { const Pair v = lds_get2(&box.rows[slot][w][lane]); d[2 * w] = bitsf(v.lo); d[2 * w + 1] = bitsf(v.hi); }
             asm volatile("" ::: "memory");
         };
         auto flush = [&]() {                             // BPR.py:58, 64 logs at a time, off the chain
@@ -584,7 +599,7 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
 #pragma unroll
                     for (int r = 0; r < KR; ++r) p[r] = d[r];
                 }
-                lds_put(&box.cw[seq & (kTrioRing - 1)][1][lane], seq);   // acknowledged: wave S does not run ahead of this wave
+                lds_put2(&box.cw[seq & (kTrioRing - 1)][lane], 0u, seq);  // acknowledged: the S waves do not run ahead of this wave
                 ++seq;
                 fetch(seq);
                 YUE_CS(cs_t0 = __builtin_readcyclecounter();)
@@ -609,9 +624,7 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
             }
             fetch(seq + 1u);                                             // the next packet's reads fly under the sigmoid
             const float c = FAST ? chain_coef_fast(x, lrf) : (float)(a.lr * (1.0 - chain_sigmoid(x)));
-            lds_putf(&box.cw[slot][0][lane], c);
-            asm volatile("" ::: "memory");
-            lds_put(&box.cw[slot][1][lane], seq);
+            lds_put2(&box.cw[slot][lane], fbits(c), seq);
 #pragma unroll
             for (int r = 0; r < KR; ++r) {                               // BPR.py:51, :55 on the user row (as bpr_elem)
                 const float td = c * dd[r];
@@ -648,8 +661,11 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
         return rp;
     };
 
-    if (wave == 2) {
-        // ---------------------------------------------------------------- wave S: item-row updates and all stores
+    if (wave == 2 || wave == 3) {
+        // ---------------------------------------------------------------- waves Si (2) / Sj (3): one item row's update and stores each
+        // (two instances of the loop: which row a wave updates is fixed at compile time, so the other row's arithmetic falls away)
+        auto stores = [&](auto which) {
+            constexpr bool neg = decltype(which)::value;
         float p[KR];
 #pragma unroll
         for (int r = 0; r < KR; ++r) p[r] = 0.0f;
@@ -675,13 +691,11 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
         float dn[2 * KR], cn;
         auto fetch = [&](unsigned q) {                   // tag before the rows, wave C's sequence number before its coefficient:
             const unsigned slot = q & (kTrioRing - 1);   // a matching tag / number vouches for what is read behind it
-            tg = lds_get(&box.pkt[slot][TAG][lane]);
-            sq = lds_get(&box.cw[slot][1][lane]);
+            { const Pair h = lds_get2(&box.hdr[slot][lane]); mvn = h.lo; tg = h.hi; }
+            { const Pair w = lds_get2(&box.cw[slot][lane]); cn = bitsf(w.lo); sq = w.hi; }
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 2 * KR; ++r) dn[r] = lds_getf(&box.pkt[slot][r][lane]);
-            mvn = lds_get(&box.pkt[slot][META][lane]);
-            cn = lds_getf(&box.cw[slot][0][lane]);
+            for (int w = 0; w < KR; ++w) { const Pair v = lds_get2(&box.rows[slot][w][lane]); dn[2 * w] = bitsf(v.lo); dn[2 * w + 1] = bitsf(v.hi); }
             asm volatile("" ::: "memory");
         };
         fetch(seq);
@@ -691,7 +705,7 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
                 asm volatile("" : "+v"(bad));
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) break;
                 // an event and its coefficient
-                lds_put(&box.sdone[lane], seq);          // behind this wave's reads of the slot (LDS order): L may reuse it
+                lds_put(&box.sdone[neg][lane], seq);     // behind this wave's reads of the slot (LDS order): the L waves may reuse it
                 float d[2 * KR];
 #pragma unroll
                 for (int r = 0; r < 2 * KR; ++r) d[r] = dn[r];
@@ -699,47 +713,59 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
                 const float c = cn;
                 ++seq;
                 fetch(seq);                              // the next packet's reads fly under this one's arithmetic
-                unsigned oi = (unsigned)__builtin_amdgcn_readlane((int)mv, 0) * row_bytes, oj = (unsigned)__builtin_amdgcn_readlane((int)mv, 1) * row_bytes;
-                const uint32_t wi1 = (uint32_t)__builtin_amdgcn_readlane((int)mv, 2) + 1u, wj1 = (uint32_t)__builtin_amdgcn_readlane((int)mv, 3) + 1u;
-                vmem_sgpr_guard(oi, oj);
+                // lanes 0..3 of the header word: positive, negative, their ordinals -- this wave's row and the version it leaves with
+                unsigned orow = (unsigned)(neg ? __builtin_amdgcn_readlane((int)mv, 1) : __builtin_amdgcn_readlane((int)mv, 0)) * row_bytes;
+                const uint32_t w1 = (uint32_t)(neg ? __builtin_amdgcn_readlane((int)mv, 3) : __builtin_amdgcn_readlane((int)mv, 2)) + 1u;
+                vmem_sgpr_guard(orow);
 #pragma unroll
                 for (int q = 0; q < GR; ++q) {
-                    const Elem o = bpr_elem(p[q], d[q], d[KR + q], c, a.ru, a.ri);    // BPR.py:51-57
+                    Elem o;
+                    if (YUE_ABL & 32) { o.p2 = p[q]; o.qi2 = d[q]; o.qj2 = c; } else o = bpr_elem(p[q], d[q], d[KR + q], c, a.ru, a.ri);    // BPR.py:51-57
                     p[q] = o.p2;
-                    if (ONE_XCD) { GT::store_l2(GT::make(o.qi2, wi1), vo[q], rq, oi); GT::store_l2(GT::make(o.qj2, wj1), vo[q], rq, oj); }
-                    else {
-                        GT::store(GT::make(o.qi2, wi1), vo[q], rq, oi);            // the positive's row first: the hotter of the two
-                        GT::store(GT::make(o.qj2, wj1), vo[q], rq, oj);
-                    }
+                    const float mine = neg ? o.qj2 : o.qi2;
+                    if (YUE_ABL & (16 | 4)) { asm volatile("" :: "v"(mine), "s"(orow)); }
+                    else if (ONE_XCD) GT::store_l2(GT::make(mine, w1), vo[q], rq, orow);
+                    else GT::store(GT::make(mine, w1), vo[q], rq, orow);
                 }
                 YUE_CS(++cs_sn;)
             }
+            YUE_CS(const unsigned long long cs_s0 = __builtin_readcyclecounter();)
             const unsigned type = (unsigned)__builtin_amdgcn_readfirstlane((int)tg) & 3u;
             const bool here = all_lanes((tg >> 2) == seq);
             if (here && type == kPktExit) break;
             if (!here || !all_lanes(sq == seq) || type == kPktEvent) {   // not published yet, or wave C has not answered yet (events: the hot loop's business)
                 if (!nap()) break;
                 fetch(seq);
+                YUE_CS(cs_swait += __builtin_readcyclecounter() - cs_s0;)
                 continue;
             }
             idle = 0;
-            lds_put(&box.sdone[lane], seq);
+            lds_put(&box.sdone[neg][lane], seq);
             if (type == kPktStart) {
 #pragma unroll
                 for (int r = 0; r < KR; ++r) p[r] = dn[r];
                 u_run = (int64_t)__builtin_amdgcn_readlane((int)mvn, 0);
                 pver1 = (uint32_t)__builtin_amdgcn_readlane((int)mvn, 1);
-            } else if (type == kPktEnd) store_user_row();    // the user row leaves NOW (a later run of the user, any group's, waits for it)
+            } else if (type == kPktEnd && !neg) store_user_row();    // the user row leaves NOW (a later run of the user, any group's, waits for it)
             ++seq;
             fetch(seq);
         }
         YUE_CS(if (lane == 0) { atomicAdd(a.stats + 5, cs_swait); atomicAdd(a.stats + 6, cs_sn); })
+        };
+        if (wave == 2) stores(std::false_type{}); else stores(std::true_type{});
         return;
     }
 
-    // -------------------------------------------------------------------- wave L: claims, headers, prefetch ring, version checks
-    unsigned seq = 1, sdone_seen = 0;
-    YUE_CS(unsigned long long cs_lfast = 0, cs_lnfast = 0, cs_lnslow = 0;)
+    // -------------------------------------------------------------------- waves L0 (0) / L1 (4): claims, headers, prefetch rings, version checks
+    // (A workgroup's waves are dealt to the CU's four SIMDs in turn, so waves 0 and 4 share one: the two loading waves, each of
+    // which works on every other triplet only -- measured per triplet: L 2 x 167 cycles, S 2 x 250, C 265 with the short coefficient.)
+    // L0 takes the even triplets of a segment of 64, L1 the odd ones, each with a ring of its own.  A triplet's packet number is
+    // the segment's first number plus the live triplets in front of it (from the ballot of the segment's headers: both waves
+    // count alike), so the two waves publish independently and waves C / S still see the run's triplets in order.
+    const unsigned par = wave == 0 ? 0u : 1u;            // 0: L0 (also: claims, start / end / exit packets), 1: L1
+    unsigned sdone_seen = 0;                             // min over the two S waves, as last read
+    unsigned next_seq = 1;                               // number of the next run's start packet
+    YUE_CS(unsigned long long cs_lfast = 0, cs_lnfast = 0, cs_lring = 0;)
 
     auto all_mine = [&](uint32_t want, const greg (&g)[GR]) -> bool {
         unsigned bad = 0u;
@@ -773,38 +799,52 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
             if (all_mine(want, g)) return true;
         }
     };
-    // the slot of packet `seq` is free once wave S is done with packet seq - kTrioRing.  false: gave up
-    auto reserve_slow = [&]() -> bool {
+    // the slot of packet `seq` is free once both S waves are done with packet seq - kTrioRing.  false: gave up
+    auto reserve_slow = [&](unsigned seq) -> bool {
+        YUE_CS(const unsigned long long cs_r0 = __builtin_readcyclecounter();)
         for (;;) {
-            sdone_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_get(&box.sdone[lane]));
-            if (seq - sdone_seen <= (unsigned)kTrioRing) { idle = 0; return true; }
+            const unsigned d0 = lds_get(&box.sdone[0][lane]), d1 = lds_get(&box.sdone[1][lane]);
+            sdone_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)((int)(d0 - d1) < 0 ? d0 : d1));
+            if ((int)(seq - sdone_seen) <= kTrioRing) { idle = 0; YUE_CS(cs_lring += __builtin_readcyclecounter() - cs_r0;) return true; }
             if (!nap()) return false;
         }
     };
-    auto publish = [&](unsigned type, const float (&v)[2 * KR], int count, unsigned mv) {
+    auto publish = [&](unsigned seq, unsigned type, const float (&v)[2 * KR], int count, unsigned mv) {
         const unsigned slot = seq & (kTrioRing - 1);
 #pragma unroll
-        for (int r = 0; r < 2 * KR; ++r) if (r < count) lds_putf(&box.pkt[slot][r][lane], v[r]);
-        lds_put(&box.pkt[slot][META][lane], mv);
+        for (int w = 0; w < KR; ++w) if (2 * w < count && !((YUE_ABL & 2) && type == kPktEvent)) lds_put2(&box.rows[slot][w][lane], fbits(v[2 * w]), fbits(v[2 * w + 1]));
         asm volatile("" ::: "memory");
-        lds_put(&box.pkt[slot][TAG][lane], (seq << 2) | type);
-        ++seq;
+        lds_put2(&box.hdr[slot][lane], mv, (seq << 2) | type);
     };
     float zeros[2 * KR];
 #pragma unroll
     for (int r = 0; r < 2 * KR; ++r) zeros[r] = 0.0f;
 
-    for (;;) {
-        unsigned long long run = 0;
-        if (lane == 0) run = atomicAdd(a.claim, 1ull);
-        run = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(run >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)run);
-        if ((int64_t)run >= a.R) break;
-        const int64_t e0 = a.run_ptr[run], e1 = a.run_ptr[run + 1];
-        if (e1 <= e0) continue;
-        const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
-        const unsigned len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
-
-        {   // the user row to waves C and S
+    for (unsigned rc = 1;; ++rc) {                       // rc: the group's run counter (slot of the mailbox)
+        int64_t e0;
+        unsigned len, seq0;                              // seq0: number of the run's start packet
+        if (par == 0) {
+            unsigned long long run = 0;
+            if (lane == 0) run = atomicAdd(a.claim, 1ull);
+            run = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(run >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)run);
+            int64_t e1 = 0;
+            e0 = 0;
+            const bool more = (int64_t)run < a.R;
+            if (more) { e0 = a.run_ptr[run]; e1 = a.run_ptr[run + 1]; }
+            len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
+            if (more && e1 <= e0) { --rc; continue; }                   // an empty run: nothing to tell anybody
+            seq0 = next_seq;
+            {   // the mailbox for L1 (a ring as long as the packet ring: L1 cannot be that many runs behind, see reserve_slow)
+                unsigned mb = rc;
+                mb = write_lane<0>(mb, (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)e0));
+                mb = write_lane<1>(mb, (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)e0 >> 32)));
+                mb = write_lane<2>(mb, more ? len : 0xffffffffu);       // (no more runs: L1 leaves)
+                mb = write_lane<3>(mb, seq0);
+                lds_put(&box.runbox[rc & (kTrioRing - 1)][lane], mb);
+            }
+            if (!more) break;
+            const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
+            // the user row to waves C and S
             float v[2 * KR];
             uint32_t pver = 0u;
 #pragma unroll
@@ -826,10 +866,23 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
             }
             unsigned mv = pver + 1u;                                     // lane 0: the user, lane 1: the version the row leaves with
             mv = write_lane<0>(mv, (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
-            if (seq - sdone_seen > (unsigned)kTrioRing && !reserve_slow()) goto bail;
-            publish(kPktStart, v, KR, mv);
+            if ((int)(seq0 - sdone_seen) > kTrioRing && !reserve_slow(seq0)) goto bail;
+            publish(seq0, kPktStart, v, KR, mv);
+        } else {
+            unsigned mb;
+            for (;;) {
+                mb = lds_get(&box.runbox[rc & (kTrioRing - 1)][lane]);
+                if ((unsigned)__builtin_amdgcn_readlane((int)mb, 4) == rc) break;
+                if (!nap()) goto bail;
+            }
+            idle = 0;
+            len = (unsigned)__builtin_amdgcn_readlane((int)mb, 2);
+            if (len == 0xffffffffu) break;
+            e0 = (int64_t)(((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mb, 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mb, 0));
+            seq0 = (unsigned)__builtin_amdgcn_readlane((int)mb, 3);
         }
 
+        unsigned seg_seq = seq0 + 1u;                    // number of the segment's first live triplet
         for (unsigned seg = 0; seg < len; seg += 64u) {
             int hAi, hAj;
             uint32_t hAwi, hAwj;
@@ -850,62 +903,74 @@ __global__ void __launch_bounds__(192) k_bpr_chain3(ChainArgs a, const int32_t *
             };
             // (the compiler's own loads above are waited for HERE, not in front of a step, where the wait would drain the ring)
             asm volatile("" : "+v"(hAi), "+v"(hAj), "+v"(hAwi), "+v"(hAwj));
+            const unsigned long long live = __builtin_amdgcn_ballot_w64(hAj >= 0);
 #pragma unroll
-            for (int s = 0; s < G; ++s) fill(s, __builtin_amdgcn_readlane(hAi, s), __builtin_amdgcn_readlane(hAj, s));
+            for (int s = 0; s < G; ++s) fill(s, __builtin_amdgcn_readlane(hAi, 2 * s + par), __builtin_amdgcn_readlane(hAj, 2 * s + par));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring is full: from here on the counted waits hold
 
             const unsigned seg_len = len - seg < 64u ? len - seg : 64u;
-            // this wave issues loads only: every step exactly 2 GR of them, so a slot's loads have (G - 1) * 2 GR younger ones
+            // a wave issues loads only: every step exactly 2 GR of them, so a slot's loads have (G - 1) * 2 GR younger ones
             // behind them when its turn comes (refills stay inside the segment of 64: the last group's reload the group itself)
-            for (unsigned ol = 0; ol < seg_len; ol += G) {
-                const unsigned nxt = ol + G < 64u ? ol + G : ol;
+            for (unsigned ol = 0; ol < seg_len; ol += 2 * G) {
+                const unsigned nxt = ol + 2 * G < 64u ? ol + 2 * G : ol;
 #pragma unroll
                 for (int s = 0; s < G; ++s) {
                     YUE_CS(const unsigned long long cs_t0 = __builtin_readcyclecounter(); bool cs_waited = false;)
-                    ring_wait<GR, (G - 1) * 2 * GR>(gi[s], gj[s]);
-                    const int tj = __builtin_amdgcn_readlane(hAj, ol + s);
-                    if (tj >= 0) {                                   // (wave-uniform) an event of the run with a negative
-                        const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, ol + s), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, ol + s);
-                        const int ti = __builtin_amdgcn_readlane(hAi, ol + s);
+                    const unsigned t = ol + 2 * s + par;             // the triplet of this step (index in the segment)
+                    if (!(YUE_ABL & 8)) ring_wait<GR, (G - 1) * 2 * GR>(gi[s], gj[s]);
+                    if ((live >> t) & 1ull) {                        // (wave-uniform) an event of the run with a negative
+                        const unsigned seq = seg_seq + (unsigned)__builtin_popcountll(live & ((1ull << t) - 1ull));
+                        const int tj = __builtin_amdgcn_readlane(hAj, t);
+                        const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hAwi, t), wj = (uint32_t)__builtin_amdgcn_readlane((int)hAwj, t);
+                        const int ti = __builtin_amdgcn_readlane(hAi, t);
                         // all granules carry their ordinals and the ring of packets has room: ONE test (xor / or in the vector ALU;
                         // the empty statement keeps the compiler from turning it back into one compare and branch per granule)
-                        unsigned bad = seq - sdone_seen > (unsigned)kTrioRing ? 1u : 0u;
+                        unsigned bad = (int)(seq - sdone_seen) > kTrioRing ? 1u : 0u;
+                        if (!(YUE_ABL & 1)) {
 #pragma unroll
-                        for (int q = 0; q < GR; ++q) bad |= (GT::version(gi[s][q]) ^ wi) | (GT::version(gj[s][q]) ^ wj);
+                            for (int q = 0; q < GR; ++q) bad |= (GT::version(gi[s][q]) ^ wi) | (GT::version(gj[s][q]) ^ wj);
+                        }
                         asm volatile("" : "+v"(bad));
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {
                             // a row does not carry its ordinal yet, or the ring of packets is full
                             unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)tj * row_bytes;
                             vmem_sgpr_guard(oi, oj);
-                            if (!all_mine(wj, gj[s]) && !acquire_slow(rq, oj, wj, gj[s])) goto bail;
-                            if (!all_mine(wi, gi[s]) && !acquire_slow(rq, oi, wi, gi[s])) goto bail;
-                            if (seq - sdone_seen > (unsigned)kTrioRing && !reserve_slow()) goto bail;
+                            if (!(YUE_ABL & 1)) {
+                                if (!all_mine(wj, gj[s]) && !acquire_slow(rq, oj, wj, gj[s])) goto bail;
+                                if (!all_mine(wi, gi[s]) && !acquire_slow(rq, oi, wi, gi[s])) goto bail;
+                            }
+                            if ((int)(seq - sdone_seen) > kTrioRing && !reserve_slow(seq)) goto bail;
                             YUE_CS(cs_waited = true;)
                         }
                         float v[2 * KR];
 #pragma unroll
                         for (int q = 0; q < GR; ++q) { v[q] = GT::value(gi[s][q]); v[KR + q] = GT::value(gj[s][q]); }
-                        unsigned mv = wj;                            // lanes 0..3: the two items, the two ordinals (wave S adds the rest)
-                        mv = write_lane<0>(mv, (unsigned)ti);
-                        mv = write_lane<1>(mv, (unsigned)tj);
-                        mv = write_lane<2>(mv, wi);
-                        publish(kPktEvent, v, 2 * KR, mv);
+                        unsigned mv = wj;                            // lanes 0..3: the two items, the two ordinals (the S waves add the rest)
+                        if (!(YUE_ABL & 4)) {
+                            mv = write_lane<0>(mv, (unsigned)ti);
+                            mv = write_lane<1>(mv, (unsigned)tj);
+                            mv = write_lane<2>(mv, wi);
+                        }
+                        publish(seq, kPktEvent, v, 2 * KR, mv);
+                        YUE_CS(if (!cs_waited) { cs_lfast += __builtin_readcyclecounter() - cs_t0; ++cs_lnfast; })
                     }
                     // refill with the same slot of the next group
-                    fill(s, __builtin_amdgcn_readlane(hAi, nxt + s), __builtin_amdgcn_readlane(hAj, nxt + s));
-                    YUE_CS(if (tj >= 0) { if (cs_waited) ++cs_lnslow; else { cs_lfast += __builtin_readcyclecounter() - cs_t0; ++cs_lnfast; } })
+                    if (!(YUE_ABL & 8)) fill(s, __builtin_amdgcn_readlane(hAi, nxt + 2 * s + par), __builtin_amdgcn_readlane(hAj, nxt + 2 * s + par));
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing of this segment's ring is in flight when the next one refills it
+            seg_seq += (unsigned)__builtin_popcountll(live);
         }
-        // end of the run: wave S stores the user row
-        if (seq - sdone_seen > (unsigned)kTrioRing && !reserve_slow()) goto bail;
-        publish(kPktEnd, zeros, 0, 0u);
+        next_seq = seg_seq + 1u;                         // (seg_seq: the run's end packet)
+        if (par == 0) {                                  // end of the run: wave Si stores the user row
+            if ((int)(seg_seq - sdone_seen) > kTrioRing && !reserve_slow(seg_seq)) goto bail;
+            publish(seg_seq, kPktEnd, zeros, 0, 0u);
+        }
     }
 bail:
-    YUE_CS(if (lane == 0) { atomicAdd(a.stats + 3, cs_lfast); atomicAdd(a.stats + 4, cs_lnfast); atomicAdd(a.stats + 7, cs_lnslow); })
-    // the other two waves leave (a full ring drains first; when this wave gave up, the status word ends their waits)
-    if (seq - sdone_seen <= (unsigned)kTrioRing || reserve_slow()) publish(kPktExit, zeros, 0, 0u);
+    YUE_CS(if (lane == 0) { atomicAdd(a.stats + 3, cs_lfast); atomicAdd(a.stats + 4, cs_lnfast); atomicAdd(a.stats + 7, cs_lring); })
+    // the other waves leave (a full ring drains first; when a wave gave up, the status word ends everybody's waits)
+    if (par == 0 && ((int)(next_seq - sdone_seen) <= kTrioRing || reserve_slow(next_seq))) publish(next_seq, kPktExit, zeros, 0, 0u);
 }
 
 }  // namespace yue
