@@ -371,6 +371,46 @@ double orc_bpr_rounds(float *P, float *Q, int64_t m, int64_t n, int k,
 }
 
 /*
+ * S-round with SEQUENTIAL USER ROWS (ours): as orc_bpr_rounds, but every triplet sees the
+ * user row as its predecessors of the same user left it -- P[u] is updated in place, event by event, exactly as the
+ * reference does (BPR.py:51, :55) -- while the ITEM rows keep round semantics: read as they were when the round started,
+ * per-row differences summed and added once.  A round of one triplet is the sequential loop (up to x + (x' - x) rounding
+ * of the two item rows).
+ */
+double orc_bpr_rounds_seq_user(float *P, float *Q, int64_t m, int64_t n, int k,
+                               const int32_t *u, const int32_t *i, const int32_t *j,
+                               const int64_t *round_ptr, int64_t n_rounds, double lr, double regU, double regI) {
+    double nll = 0.0;
+    float *dQ = (float *)calloc((size_t)n * k, sizeof(float));
+    (void)m;
+    for (int64_t r = 0; r < n_rounds; r++) {
+        for (int64_t t = round_ptr[r]; t < round_ptr[r + 1]; t++) {
+            if (j[t] < 0) continue;
+            float *p = P + (int64_t)u[t] * k;
+            const float *qi = Q + (int64_t)i[t] * k, *qj = Q + (int64_t)j[t] * k;
+            coef_t cf = coef(p, qi, qj, k, lr, regU, regI);
+            float *dqi = dQ + (int64_t)i[t] * k, *dqj = dQ + (int64_t)j[t] * k;
+            for (int e = 0; e < k; e++) {
+                float p2, qi2, qj2;
+                upd1(p[e], qi[e], qj[e], cf, &p2, &qi2, &qj2);
+                p[e] = p2; dqi[e] += qi2 - qi[e]; dqj[e] += qj2 - qj[e];
+            }
+            nll += -log(cf.s);
+        }
+        for (int64_t t = round_ptr[r]; t < round_ptr[r + 1]; t++) {
+            if (j[t] < 0) continue;
+            int64_t rows[2] = { (int64_t)i[t], (int64_t)j[t] };
+            for (int w = 0; w < 2; w++) {
+                float *x = Q + rows[w] * k, *d = dQ + rows[w] * k;
+                for (int e = 0; e < k; e++) { x[e] += d[e]; d[e] = 0.0f; }
+            }
+        }
+    }
+    free(dQ);
+    return nll;
+}
+
+/*
  * One round's summed differences WITHOUT applying them (factors untouched): what one rank
  * contributes for a user block when items are sharded over several GPUs (multi-GPU).
  * dP[m*k] and dQ[n*k] must be zero on entry.  Returns the round's sum of -log(s).

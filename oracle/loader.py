@@ -36,6 +36,7 @@ class Oracle(object):
         L.orc_bpr_round_deltas.restype = C.c_double
         L.orc_topn_scan.restype = C.c_int
         L.orc_dependency_depth.restype = C.c_int64
+        L.orc_bpr_rounds_seq_user.restype = C.c_double
         L.orc_dataflow_model.restype = C.c_double
 
     # -- samplers -------------------------------------------------------------
@@ -96,6 +97,14 @@ class Oracle(object):
         u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
         rp = np.ascontiguousarray(round_ptr, np.int64)
         return self.lib.orc_bpr_rounds(_p(P, C.c_float), _p(Q, C.c_float), C.c_int64(P.shape[0]), C.c_int64(Q.shape[0]), C.c_int(P.shape[1]),
+                                       _p(u, C.c_int32), _p(i, C.c_int32), _p(j, C.c_int32), _p(rp, C.c_int64), C.c_int64(len(rp) - 1),
+                                       C.c_double(lr), C.c_double(regU), C.c_double(regI))
+
+    def bpr_rounds_seq_user(self, P, Q, u, i, j, round_ptr, lr, regU, regI):
+        assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous
+        u, i, j = (np.ascontiguousarray(x, np.int32) for x in (u, i, j))
+        rp = np.ascontiguousarray(round_ptr, np.int64)
+        return self.lib.orc_bpr_rounds_seq_user(_p(P, C.c_float), _p(Q, C.c_float), C.c_int64(P.shape[0]), C.c_int64(Q.shape[0]), C.c_int(P.shape[1]),
                                        _p(u, C.c_int32), _p(i, C.c_int32), _p(j, C.c_int32), _p(rp, C.c_int64), C.c_int64(len(rp) - 1),
                                        C.c_double(lr), C.c_double(regU), C.c_double(regI))
 

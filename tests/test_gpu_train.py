@@ -16,8 +16,41 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+_SEQ = [1]
+
+
+@pytest.fixture(scope='module', params=[1, 0], ids=['user_rows_sequential', 'user_rows_per_round'], autouse=True)
+def user_rows(request):
+    """The whole module runs twice: with the epoch path's default on one GPU -- a wave owns a user and walks the user's events in
+    order (k_round_u; oracle: orc_bpr_rounds_seq_user) -- and with user rows under round semantics (option round_user_seq = 0:
+    k_round_m + dP, the form a communicator runs; oracle: orc_bpr_rounds).  Every Device of the module gets the option."""
+    from yue_amd import _shim
+    orig = _shim.Device.__init__
+
+    def init(self, *a, **k):
+        orig(self, *a, **k)
+        self.set_option('round_user_seq', request.param)
+        self.set_option('round_fast', 0)      # the reference's double-precision sigmoid in k_round_u too: the tight bounds of this module hold (the default, a single-precision coefficient, has a test of its own below)
+    _shim.Device.__init__ = init
+    _SEQ[0] = request.param
+    yield request.param
+    _shim.Device.__init__ = orig
+    _SEQ[0] = 1
+
+
+def _epoch_oracle(orc, meta=1):
+    """the restatement of what yue_bpr_epoch runs on one GPU under the module's current option (round_meta = 0, the kernel that
+    counts and retires inside the round launches, keeps user rows under round semantics)"""
+    return orc.bpr_rounds_seq_user if _SEQ[0] and meta else orc.bpr_rounds
+
+
+def _heavy():
+    if not _SEQ[0]:
+        pytest.skip('BASELINE-size case: run once, under the default')
+
+
 @pytest.fixture(scope='module')
-def dev():
+def dev(user_rows):
     from yue_amd._shim import Device
     d = Device(0, raise_errors=True)
     yield d
@@ -158,7 +191,7 @@ def test_fused_epoch_matches_oracle(dev, orc, m, n, d, k, W):
         j_orc = orc.sample_counter(seed, epoch, ev_u, n, data['indptr'], data['indices'])
         assert np.array_equal(j_gpu, j_orc)
         nll, sp, sq = dev.bpr_epoch(seed, epoch, W, 0.02, 0.01, 0.01)
-        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j_orc, rp, 0.02, 0.01, 0.01)
+        nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j_orc, rp, 0.02, 0.01, 0.01)
         P, Q = dev.get_factors()
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
         assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
@@ -184,7 +217,7 @@ def test_round_kernel_under_heavy_contention_and_many_wave_passes(orc, tpw):
     for epoch in range(2):
         j = orc.sample_counter(5, epoch, ev_u, n, data['indptr'], data['indices'])
         nll, _, _ = dev.bpr_epoch(5, epoch, W, 0.01, 0.01, 0.01)
-        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.01, 0.01, 0.01)
+        nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.01, 0.01, 0.01)
         P, Q = dev.get_factors()
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
         assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
@@ -197,11 +230,13 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
     from yue_amd._shim import Device
     m, n, d, k, W = 4000, 2500, 25, 128, 8192
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=21)
-    Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
     rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     j = orc.sample_counter(9, 0, ev_u, n, data['indptr'], data['indices'])
-    nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+    ref = {}
+    for meta_ in (1, 0):
+        Po, Qo = P0.copy(), Q0.copy()
+        ref[meta_] = (_epoch_oracle(orc, meta_)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01), Po, Qo)
     # (with round_meta 1 also 2..64: staged up to that many touches per row -- W = 8,192 events on 2,500 items: 6.5
     # touches per row and round on average, blocks of every size up to 64 occur);
     # round_meta: touch metadata from the per-epoch pre-pass + fold launches (default) vs touches counted and contended
@@ -216,6 +251,7 @@ def test_tuning_knobs_do_not_change_the_epoch(orc):
         nll, _, _ = dev.bpr_epoch(9, 0, W, 0.02, 0.01, 0.01)
         P, Q = dev.get_factors()
         dev.close()
+        nll_o, Po, Qo = ref[meta]
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (tpw, stage, meta)
 
 
@@ -247,16 +283,20 @@ def test_epoch_metadata_pre_pass_over_several_item_ranges(orc):
     m, n, d, k, W = 12000, 100000, 40, 32, 16384
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=5)
     rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
-    Po, Qo = P0.copy(), Q0.copy()
-    ref = []
-    for epoch in range(2):
-        j = orc.sample_counter(13, epoch, ev_u, n, data['indptr'], data['indices'])
-        ref.append(orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.03, 0.01, 0.01))
+    refs = {}
+    for meta in (1, 0):
+        Po, Qo = P0.copy(), Q0.copy()
+        ref = []
+        for epoch in range(2):
+            j = orc.sample_counter(13, epoch, ev_u, n, data['indptr'], data['indices'])
+            ref.append(_epoch_oracle(orc, meta)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.03, 0.01, 0.01))
+        refs[meta] = (ref, Po, Qo)
     touched = np.bincount(np.concatenate([data['ev_i'][:W], j[:W]]), minlength=n)
     assert (touched == 1).sum() > 1000 and ((touched >= 2) & (touched <= 4)).sum() > 1000 and (touched > 4).sum() > 30
     for meta in (1, 0):
         dev = Device(0, raise_errors=True)
         dev.set_option('round_meta', meta)
+        ref, Po, Qo = refs[meta]
         dev.set_factors(P0, Q0)
         dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
         for epoch in range(2):
@@ -268,6 +308,7 @@ def test_epoch_metadata_pre_pass_over_several_item_ranges(orc):
 
 
 def test_epoch_path_on_a_large_catalogue(orc):
+    _heavy()
     # more item rows than the plain pre-pass takes (454,656): a round's touches are bucketed by item range first
     # (k_round_bucket), 19 ranges of 32,768 rows here; sparse touches (most rows untouched) and a popular head
     from yue_amd._shim import Device
@@ -282,7 +323,7 @@ def test_epoch_path_on_a_large_catalogue(orc):
     for epoch in range(2):
         j = orc.sample_counter(21, epoch, ev_u, n, data['indptr'], data['indices'])
         nll, _, _ = dev.bpr_epoch(21, epoch, W, 0.03, 0.01, 0.01)
-        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.03, 0.01, 0.01)
+        nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.03, 0.01, 0.01)
         P, Q = dev.get_factors()
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), epoch
     dev.close()
@@ -309,7 +350,7 @@ def test_default_round_size_is_one_resident_wave_set(orc):
     j = orc.sample_counter(3, 0, ev_u, n, data['indptr'], data['indices'])
     rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
     Po, Qo = P0.copy(), Q0.copy()
-    nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+    nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
     assert rel_err(out[0][1], Po) < TOL and rel_err(out[0][2], Qo) < TOL and abs(out[0][0] - nll_o) <= 1e-9 * abs(nll_o)
 
 
@@ -360,13 +401,14 @@ def test_fused_epoch_skips_unsampleable_and_empty_users(dev, orc):
     nll, _, _ = dev.bpr_epoch(77, 0, 16, 0.02, 0.01, 0.01)
     Po, Qo = P0.copy(), Q0.copy()
     rp = np.array(epoch_round_ptr(ev_ptr, 16), np.int64)
-    nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j_orc, rp, 0.02, 0.01, 0.01)
+    nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, ev_i, j_orc, rp, 0.02, 0.01, 0.01)
     P, Q = dev.get_factors()
     assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
     assert np.array_equal(P[1], P0[1])
 
 
 def test_user_factors_beyond_two_gib(orc):
+    _heavy()
     # BASELINE config 4 keeps 10M x 128 user factors (5 GB) on every GPU: the round kernel addresses P and
     # dP with 31-bit offsets relative to the smallest user of a wave's batch.  Here 4.3M users x 128 = 2.2 GB.
     from yue_amd._shim import Device
@@ -387,7 +429,7 @@ def test_user_factors_beyond_two_gib(orc):
         P, Q = dev.get_factors()
         Po, Qo = P0.copy(), Q0.copy()
         rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
-        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+        nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o)
         assert rel_err(P[-1000:], Po[-1000:]) < TOL and not np.array_equal(P[-1000:], P0[-1000:])
         assert abs(sp - orc.sumsq(P)) <= 1e-12 * sp
@@ -408,6 +450,7 @@ def test_user_factors_beyond_two_gib(orc):
 
 
 def test_full_size_properties(dev):
+    _heavy()
     # BASELINE config 2 shape (100K x 50K, k=64): size-independent properties instead of the oracle
     m, n, d, k = 100000, 50000, 50, 64
     data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=20260001)
@@ -479,7 +522,7 @@ def test_epoch_path_on_random_shapes(orc, case, k, W):
         for epoch in range(2):
             j = orc.sample_counter(77, epoch, ev_u, n, indptr, indices)
             nll, sp, sq = dev.bpr_epoch(77, epoch, W, 0.03, 0.01, 0.02)
-            nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.03, 0.01, 0.02)
+            nll_o = _epoch_oracle(orc, meta)(Po, Qo, ev_u, ev_i, j, rp, 0.03, 0.01, 0.02)
             P, Q = dev.get_factors()
             assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL, (case, m, n, k, W, epoch, meta, bucket)
             assert abs(nll - nll_o) <= 1e-8 * max(abs(nll_o), 1e-30), (case, m, n, k, W, epoch, meta, bucket)
@@ -497,7 +540,7 @@ def test_one_device_serves_problems_of_different_sizes_in_turn(dev, orc):
         for epoch in range(2):
             j = orc.sample_counter(6, epoch, ev_u, n, data['indptr'], data['indices'])
             nll, _, _ = dev.bpr_epoch(6, epoch, W, 0.02, 0.01, 0.01)
-            nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+            nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
             P, Q = dev.get_factors()
             assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (m, n, k, W, epoch)
 
@@ -513,7 +556,7 @@ def test_round_size_may_change_between_epochs_on_one_device(dev, orc):
         rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
         j = orc.sample_counter(4, epoch, ev_u, n, data['indptr'], data['indices'])
         nll, _, _ = dev.bpr_epoch(4, epoch, W, 0.02, 0.01, 0.01)
-        nll_o = orc.bpr_rounds(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+        nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
         P, Q = dev.get_factors()
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * abs(nll_o), (epoch, W)
 
@@ -541,7 +584,7 @@ def test_degenerate_shapes(orc, m, n, k):
     Po, Qo = P0.copy(), Q0.copy()
     E = len(ev_u)
     rp = np.array(epoch_round_ptr(ev_ptr, 3), np.int64)
-    nll_o = orc.bpr_rounds(Po, Qo, ev_u, ev_i, j, rp, 0.05, 0.01, 0.02)
+    nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, ev_i, j, rp, 0.05, 0.01, 0.02)
     P, Q = dev.get_factors()
     assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL and abs(nll - nll_o) <= 1e-9 * max(abs(nll_o), 1e-30)
     dev.set_factors(P0, Q0)
@@ -560,3 +603,32 @@ def test_degenerate_shapes(orc, m, n, k):
         assert rc == 0 and np.array_equal(ids, oid) and np.array_equal(sc, osc)
         assert np.array_equal(dev.scores(0), orc.scores(P, Q, 0))
     dev.close()
+
+
+def test_epoch_with_the_single_precision_coefficient_stays_within_tolerance(orc):
+    """The epoch path's default on one GPU (k_round_u with option round_fast = 1: the step's coefficient lr (1 - sigmoid(x)) in
+    single precision) against the restatement with the reference's double-precision sigmoid: factors within 1e-5 after two
+    epochs, the loss (double-precision sigmoids of the device's own margins) within 1e-6."""
+    if not _SEQ[0]:
+        pytest.skip('k_round_u only')
+    from yue_amd._shim import Device
+    for (m, n, d, k, W) in [(2000, 3000, 50, 128, 8192), (500, 257, 30, 64, 1000), (300, 400, 20, 200, 128)]:
+        data = synth.make_arrays(m, n, d, seed=11)
+        ev_u = np.repeat(np.arange(m, dtype=np.int32), np.diff(data['ev_ptr']))
+        P0, Q0 = synth.init_factors(m, n, k, 12)
+        dev = Device(0, raise_errors=True)
+        dev.set_option('round_fast', 1)
+        dev.set_factors(P0, Q0)
+        dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+        rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
+        Po, Qo = P0.copy(), Q0.copy()
+        for epoch in range(2):
+            j = dev.sample_negatives(3, epoch)
+            nll, _, _ = dev.bpr_epoch(3, epoch, W, 0.02, 0.01, 0.01)
+            assert dev.get_option('round_last_user_seq') == 1
+            nll_o = orc.bpr_rounds_seq_user(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+            assert abs(nll - nll_o) <= 1e-6 * abs(nll_o)
+        P, Q = dev.get_factors()
+        dev.close()
+        print('k=%d: rel P %.2e Q %.2e, bit-equal P %.3f Q %.3f' % (k, rel_err(P, Po), rel_err(Q, Qo), np.mean(P == Po), np.mean(Q == Qo)))
+        assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL

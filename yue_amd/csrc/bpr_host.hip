@@ -218,6 +218,17 @@ int launch_round_meta(yue_ctx *c, const yue::TrainArgs &a, const std::vector<int
     return YUE_OK;
 }
 
+void launch_round_fold(yue_ctx *c, const yue::TrainArgs &a, int64_t e0, int64_t e1, int64_t round_index) {
+    yue::FoldArgs f{};
+    f.fold = c->fold.p + yue::fold_base(e0, round_index); f.round_rows = c->round_rows.p + round_index; f.Q = a.Q; f.dQ = a.dQ; f.stage = a.stage; f.k = c->k; f.capacity = (uint32_t)((e1 - e0) & ~(int64_t)3);
+    const dim3 fgrid((unsigned)std::min<int64_t>(c->opt_fold_blocks, std::max<int64_t>(1, (e1 - e0 + 15) / 16))), block(256);
+    switch (kr_of(c->k)) {
+        case 1: hipLaunchKernelGGL(yue::k_round_fold<1>, fgrid, block, 0, c->stream, f); break;
+        case 2: hipLaunchKernelGGL(yue::k_round_fold<2>, fgrid, block, 0, c->stream, f); break;
+        default: hipLaunchKernelGGL(yue::k_round_fold<4>, fgrid, block, 0, c->stream, f); break;
+    }
+}
+
 int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e1, int64_t round_index) {
     yue::RoundMArgs ra{};
     ra.e_begin = e0; ra.e_end = e1; ra.staged = c->staged ? 1 : 0;
@@ -260,23 +271,34 @@ int launch_round_m(yue_ctx *c, const yue::TrainArgs &a_in, int64_t e0, int64_t e
         default: return fail(YUE_ERR_ARG, "unsupported (k, TPW) combination");
     }
 #undef YUE_RM
-    {
-        yue::FoldArgs f{};
-        f.fold = c->fold.p + yue::fold_base(e0, round_index); f.round_rows = c->round_rows.p + round_index; f.Q = a.Q; f.dQ = a.dQ; f.stage = a.stage; f.k = c->k; f.capacity = (uint32_t)((e1 - e0) & ~(int64_t)3);
-        const dim3 fgrid((unsigned)std::min<int64_t>(c->opt_fold_blocks, std::max<int64_t>(1, (e1 - e0 + 15) / 16)));
-        switch (kr_of(c->k)) {
-            case 1: hipLaunchKernelGGL(yue::k_round_fold<1>, fgrid, block, 0, c->stream, f); break;
-            case 2: hipLaunchKernelGGL(yue::k_round_fold<2>, fgrid, block, 0, c->stream, f); break;
-            default: hipLaunchKernelGGL(yue::k_round_fold<4>, fgrid, block, 0, c->stream, f); break;
-        }
+    launch_round_fold(c, a, e0, e1, round_index);
+    return YUE_OK;
+}
+
+// The S-round update launch with sequential user rows (k_round_u: one wave per user of the round) + the fold launch.
+int launch_round_u(yue_ctx *c, const yue::TrainArgs &a, int64_t u0, int64_t u1, int64_t e0, int64_t e1, int64_t round_index) {
+    yue::RoundUArgs ra{};
+    ra.u_begin = u0; ra.u_end = u1; ra.ev_ptr = c->d_ev_ptr.p; ra.e_begin = e0; ra.e_end = e1; ra.staged = c->staged ? 1 : 0; ra.margins = c->margins.p;
+    const int64_t blocks = (u1 - u0 + 3) / 4;
+    if (blocks == 0) return YUE_OK;
+    const dim3 grid((unsigned)blocks), block(256);
+    const uint32_t *mi = c->meta_i.p, *mj = c->meta_j.p;
+#define YUE_RU(KR_) do { if (c->opt_round_fast) hipLaunchKernelGGL((yue::k_round_u<KR_, true>), grid, block, 0, c->stream, a, ra, a.ev_i, a.ev_j, mi, mj); \
+                         else hipLaunchKernelGGL((yue::k_round_u<KR_, false>), grid, block, 0, c->stream, a, ra, a.ev_i, a.ev_j, mi, mj); } while (0)
+    switch (kr_of(c->k)) {
+        case 1: YUE_RU(1); break;
+        case 2: YUE_RU(2); break;
+        default: YUE_RU(4); break;
     }
+#undef YUE_RU
+    launch_round_fold(c, a, e0, e1, round_index);
     return YUE_OK;
 }
 
 // Runs the non-empty rounds bounds[r]..bounds[r+1] in order.  after_round(r) is called once the
 // launches of round r are queued (the communicator path hooks its all-reduce there).
 template <typename F>
-int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int apply_p, F after_round, bool meta = false) {
+int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds, int apply_p, F after_round, bool meta = false, const std::vector<int64_t> *user_blocks = nullptr) {
     const int64_t R = (int64_t)bounds.size() - 1;
     // staging rows: two per event of the largest round, addressed with 31-bit byte offsets
     int64_t widest = 0;
@@ -334,7 +356,10 @@ int run_rounds(yue_ctx *c, yue::TrainArgs a, const std::vector<int64_t> &bounds,
             const int64_t e0 = bounds[(size_t)r], e1 = bounds[(size_t)r + 1];
             int64_t n0 = 0, n1 = 0;
             if (pos + 1 < ne.size()) { n0 = bounds[(size_t)ne[pos + 1]]; n1 = bounds[(size_t)ne[pos + 1] + 1]; }
-            if ((rc = meta ? launch_round_m(c, a, e0, e1, r) : launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), apply_p))) return rc;
+            // (user_blocks: the rounds are blocks of whole users and this GPU holds all their events -- sequential user rows)
+            const bool seq_user = meta && user_blocks && !c->bigq;
+            if ((rc = seq_user ? launch_round_u(c, a, (*user_blocks)[(size_t)r], (*user_blocks)[(size_t)r + 1], e0, e1, r)
+                      : meta ? launch_round_m(c, a, e0, e1, r) : launch_round(c, a, e0, e1, n0, n1, (int)(pos & 1), apply_p))) return rc;
             ++pos;
         }
         if ((rc = after_round(r))) return rc;
@@ -633,7 +658,21 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
     ublock.push_back(c->m); bounds.push_back(E);
     const int64_t R = (int64_t)ublock.size() - 1;
+    // One GPU: the rank holds all events of a user, one wave can walk them in order -- sequential user rows (k_round_u), nothing
+    // left in dP.  (A communicator spreads a user's events over the ranks by item shard: there the user rows keep round semantics
+    // and dP carries their differences to the all-reduce.)
+    const bool seq_user = !yue_host::on_communicator(c) && c->opt_round_user_seq && meta_path_fits(c);
+    if (seq_user) {
+        HIPCHK(c->d_ev_ptr.resize((size_t)c->m + 1));
+        if (!c->d_ev_ptr_valid) {
+            HIPCHK(hipMemcpyAsync(c->d_ev_ptr.p, c->h_ev_ptr.data(), ((size_t)c->m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            c->d_ev_ptr_valid = true;
+        }
+        HIPCHK(c->margins.resize((size_t)std::max<int64_t>(E, 1)));
+    }
+    c->last_round_user_seq = 0;
     auto after = [&](int64_t r) -> int {
+        if (seq_user && !c->bigq) { c->last_round_user_seq = 1; return YUE_OK; }          // (bigq is set by run_rounds before the first round)
         if ((r + 1) % group != 0 && r + 1 != R) return YUE_OK;
         const int64_t g_first = ublock[(size_t)(r - (r % group))], g_last = ublock[(size_t)r + 1];
         const int64_t first = g_first * c->k, count = (g_last - g_first) * c->k;
@@ -654,7 +693,9 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         return YUE_OK;
     };
     c->comm_collectives = 0; c->comm_bytes = 0.0; c->comm_wait_ms = 0.0;
-    if ((rc = run_rounds(c, a, bounds, 0, after, meta_path_fits(c)))) { reset_round_state(c); return rc; }
+    if ((rc = run_rounds(c, a, bounds, 0, after, meta_path_fits(c), seq_user ? &ublock : nullptr))) { reset_round_state(c); return rc; }
+    if (c->last_round_user_seq && E > 0)      // the loss of the epoch from the margins k_round_u left
+        hipLaunchKernelGGL(yue::k_loss_margins, dim3(2048), dim3(256), 0, c->stream, c->margins.p, c->ev_j.p, E, c->scal.p);
     // the epoch's user rows must be complete before the loss sums and before the next epoch reads P
     if (yue_host::on_communicator(c)) {       // how long the compute stream has to wait for the last group's all-reduce + apply
         HIPCHK(hipEventRecord(c->ev_t_rounds, c->stream));
@@ -755,6 +796,9 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "round_stage") *value = c->opt_round_stage;
     else if (key == "round_last_stage_max") *value = c->last_stage_max;
     else if (key == "round_meta") *value = c->opt_round_meta;
+    else if (key == "round_user_seq") *value = c->opt_round_user_seq;
+    else if (key == "round_fast") *value = c->opt_round_fast;
+    else if (key == "round_last_user_seq") *value = c->last_round_user_seq;
     else if (key == "round_bucket") *value = c->opt_round_bucket;
     else if (key == "fold_blocks") *value = c->opt_fold_blocks;
     else if (key == "round_tpw") *value = c->opt_round_tpw;
@@ -790,6 +834,8 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
         c->opt_round_stage = (int)value; return YUE_OK;
     }
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
+    if (key == "round_user_seq") { c->opt_round_user_seq = value != 0; return YUE_OK; }
+    if (key == "round_fast") { c->opt_round_fast = value != 0; return YUE_OK; }
     if (key == "epoch_exact") { c->opt_epoch_exact = value != 0; return YUE_OK; }
     if (key == "replay_levels") { c->opt_replay_levels = value != 0; return YUE_OK; }
     if (key == "chain_split") { if (value < -1 || value > 1) return fail(YUE_ERR_ARG, "yue_set_option: chain_split must be -1, 0 or 1"); c->opt_chain_split = (int)value; return YUE_OK; }

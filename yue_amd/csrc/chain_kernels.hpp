@@ -138,65 +138,6 @@ __global__ void __launch_bounds__(256) k_chain_runs(const int32_t *ev_u, const u
     if (t == T - 1) run_ptr[incl[t]] = T;
 }
 
-// exp(y) in double for |y| <= 700, as a SHORT dependency chain: this value sits on the critical path of every triplet (the
-// epoch's time is its longest chain of dependent triplets times the latency of one).  Cody-Waite reduction y = n ln2 + r,
-// |r| <= ln2 / 2, the degree-13 Taylor polynomial of exp(r) by Estrin's scheme (4 levels of independent fused multiply-adds
-// instead of 13 dependent ones), ldexp.  Error about 1 ulp -- like the libm value the reference's math.exp returns, it is the
-// fp32 rounding of lr * (1 - s) that enters the factors (a 1-ulp difference in exp moves that rounding once in ~1e8 triplets).
-__device__ __forceinline__ double chain_exp(double y) {
-    const double n = __builtin_rint(y * 1.4426950408889634074);
-    double r = __builtin_fma(-n, 6.93147180369123816490e-01, y);
-    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    const double r2 = r * r;
-    const double a0 = __builtin_fma(r, 1.0, 1.0), a1 = __builtin_fma(r, 1.0 / 6.0, 0.5), a2 = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0),
-                 a3 = __builtin_fma(r, 1.0 / 5040.0, 1.0 / 720.0), a4 = __builtin_fma(r, 1.0 / 362880.0, 1.0 / 40320.0),
-                 a5 = __builtin_fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0), a6 = __builtin_fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
-    const double r4 = r2 * r2;
-    const double b0 = __builtin_fma(a1, r2, a0), b1 = __builtin_fma(a3, r2, a2), b2 = __builtin_fma(a5, r2, a4);
-    const double r8 = r4 * r4;
-    const double c0 = __builtin_fma(b1, r4, b0), c1 = __builtin_fma(a6, r4, b2);
-    return __builtin_ldexp(__builtin_fma(c1, r8, c0), (int)n);
-}
-// 1 / d for a finite d >= 1: hardware reciprocal, two Newton steps, one residual correction (faithful; the division the
-// reference performs is correctly rounded: the two agree except in rare last-bit cases, see chain_exp).
-__device__ __forceinline__ double chain_rcp(double d) {
-    double y = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(e, y, y);
-    e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(e, y, y);
-    e = __builtin_fma(-d, y, 1.0);
-    return __builtin_fma(e, y, y);
-}
-
-// sigmoid of the fp32 margin in double (qmath.py:115-116), as every exact kernel and the loss use it
-__device__ __forceinline__ double chain_sigmoid(float x) {
-    const double xd = (double)x;
-    if (__builtin_fabs(xd) <= 700.0) return chain_rcp(1.0 + chain_exp(-xd));
-    return 1.0 / (1.0 + exp(-xd));
-}
-// fp32(lr (1 - sigmoid(x))) = lr / (1 + e^x) in SINGLE precision -- the short form of the step's coefficient (option
-// chain_fast): five instructions on the dependency chain (v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul) instead of ~35
-// double-precision ones.  Not bit-equal to the reference's value: v_exp_f32 and v_rcp_f32 are good to 1 ulp, the rounding of
-// x log2 e adds |x| * 6e-8 relative -- a few ulp of c for the margins that occur, against north_star's 1e-5 on the factors
-// (measured: tests/test_gpu_exact.py, tests/test_gpu_baseline_configs.py).
-__device__ __forceinline__ float chain_coef_fast(float x, float lr) {
-    // (an infinite e^x gives 0, a vanishing one gives lr, a NaN margin stays a NaN -- the reference aborts on a NaN loss)
-    return lr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f));
-}
-
-// Sum over the 64 lanes in NO particular order (option chain_fast only; wave_sum keeps the oracle's order): four DPP-fused
-// adds give every lane its row's sum, row_bcast15 / row_bcast31 carry the row sums up, lane 63 holds the total.
-__device__ __forceinline__ float wave_sum_any(float v) {
-    v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = v + dpp_mov<0x141>(v);      // row_half_mirror
-    v = v + dpp_mov<0x140>(v);      // row_mirror
-    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1, 3
-    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2, 3
-    return rdlane(v, 63);
-}
-
 // An SGPR written by the vector ALU (v_readlane, v_readfirstlane) may be read by a vector-memory instruction only 5 wait
 // states later.  The compiler counts them for its own instructions but does not see into inline assembly: every scalar
 // operand of the assembly loads / stores below (descriptors, row offsets) that can come out of the vector ALU passes through

@@ -56,7 +56,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     if (c->ev_chain1) (void)hipEventDestroy(c->ev_chain1);
     if (c->ev_scan1) (void)hipEventDestroy(c->ev_scan1);
     for (auto &pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release();
+    c->P.release(); c->Q.release(); c->dP.release(); c->dQ.release(); c->margins.release();
     c->cnt0.release(); c->cnt1.release(); c->cntp0.release(); c->cntp1.release();
     c->tab0.release(); c->tab1.release();
     c->meta_i.release(); c->meta_j.release(); c->round_rows.release(); c->d_bounds.release(); c->fold.release(); c->bk_touch.release(); c->bk_ptr.release();

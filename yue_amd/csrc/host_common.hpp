@@ -60,6 +60,7 @@ struct yue_ctx {
     int k = 0;
     bool have_factors = false, have_inter = false;
     DevBuf<float> P, Q, dP, dQ;
+    DevBuf<float> margins;                       // [E] the events' margins of the running epoch (k_round_u -> k_loss_margins)
     DevBuf<unsigned long long> cnt0, cnt1;       // item-row touch counters of the even / odd round (total | remaining)
     DevBuf<uint32_t> cntp0, cntp1;               // user-row flushes of the even / odd round
     DevBuf<uint32_t> tab0, tab1;                 // staging-slot tables of the even / odd round (kStageMax words per item row)
@@ -109,6 +110,9 @@ struct yue_ctx {
     int opt_round_stage = 1;             // 0: every contended item row goes through float atomics (no staging rows); 1: sized from the round's mean touches per row; 2..64: rows with up to that many touches are staged (epoch path)
     int opt_round_bucket = 0;            // 1: the bucketed pre-pass also for small catalogues (tests)
     int opt_fold_blocks = 1536;           // workgroups of k_round_fold
+    int opt_round_user_seq = 1;          // epoch path on one GPU: 1 = a wave owns a user and walks the user's events in order (k_round_u); 0 = user rows with round semantics (k_round_m + dP)
+    int opt_round_fast = 1;              // k_round_u: the step's coefficient in single precision (0: the reference's double-precision sigmoid)
+    int last_round_user_seq = 0;         // the last epoch ran k_round_u (read-only option round_last_user_seq)
     int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
     // kernel timing
     int timing_stride = 0;

@@ -467,6 +467,137 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) k_ro
     YUE_STAMP(7, "s_waitcnt vmcnt(0)");
 }
 
+// The S-round update launch with SEQUENTIAL USER ROWS (round 4; one GPU: a user's events all lie in one round and on one rank).
+// k_round_m evaluates every triplet of a round on the round-start factors, so a user's ~50 events of an epoch take ONE summed
+// step of P[u] -- that, not the staleness of the item rows, is most of the distance between S-round and the reference's loop
+// (the P column does not depend on W).  Here one wave owns one user of the round and walks the user's
+// events in order with P[u] in registers, exactly as the reference does (BPR.py:50-51, :55); the item rows keep round semantics
+// (read as the round started; in place / staging row / float atomics by the pre-pass's metadata, finished by k_round_fold).
+// P[u] is stored in place when the user is done: no dP, no float atomics on user rows, no k_apply_range.
+// Oracle: oracle/bpr_oracle.c: orc_bpr_rounds_seq_user (a round of one event = the reference's loop).
+// FAST: the step's coefficient in single precision (chain_coef_fast: five instructions instead of ~35 double-precision ones on
+// all lanes -- k_round_m computes eight sigmoids at once in the lanes, a chain of dependent events cannot).  The loss is summed
+// from double-precision sigmoids of the events' margins, which this kernel leaves in a buffer for k_loss_margins (one pass per epoch).
+struct RoundUArgs {
+    int64_t u_begin, u_end;      // users of the round: one wave each
+    const int64_t *ev_ptr;       // [m + 1] first event of a user
+    int64_t e_begin, e_end;      // events of the round (size of the staging area)
+    int staged;
+    float *margins;              // [E] the events' margins x (BPR.py:50), for the loss (k_loss_margins)
+};
+
+template <int KR, bool FAST>
+__global__ void __launch_bounds__(256) k_round_u(TrainArgs a, RoundUArgs ra, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
+                                                 const uint32_t *__restrict__ mti, const uint32_t *__restrict__ mtj) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t u = ra.u_begin + wave;
+    if (u >= ra.u_end) return;
+    const int64_t e0 = ra.ev_ptr[u], e1 = ra.ev_ptr[u + 1];
+    if (e1 <= e0) return;
+    const unsigned k = (unsigned)a.k;
+    const unsigned row_bytes = k * 4u;
+    unsigned vo[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; vo[r] = e < k ? e * 4u : kOobOffset; }
+    const uint64_t qbytes = (uint64_t)a.n * row_bytes;
+    const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
+    const unsigned stage0 = (unsigned)a.n * row_bytes;   // the staging rows lie behind the n item rows in the same allocation
+    const uint64_t qsbytes = qbytes + (ra.staged ? 2ull * (uint64_t)(ra.e_end - ra.e_begin) * row_bytes : 0ull);
+    const int qsrec = (int)(qsbytes < 0x7fffffffull ? qsbytes : 0x7fffffffull);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(a.Q, 0, qsrec, kRsrcFlags);
+    const auto rsdQ = __builtin_amdgcn_make_buffer_rsrc(a.dQ, 0, qrec, kRsrcFlags);
+    float *prow = a.P + (uint64_t)u * k;
+    float p[KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; p[r] = e < k ? prow[e] : 0.0f; }
+    const float lrf = (float)a.lr;
+    const unsigned len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
+    for (unsigned seg = 0; seg < len; seg += 64u) {
+        // the segment's headers in the lanes of four registers (one vector load each), a v_readlane per use
+        int hI, hJ;
+        uint32_t hMI, hMJ;
+        {
+            const bool ex = seg + (unsigned)lane < len;
+            const int64_t e = e0 + seg + (ex ? lane : 0);
+            hI = evi[e]; hJ = evj[e]; hMI = mti[e]; hMJ = mtj[e];
+            if (!ex) { hI = 0; hJ = -1; hMI = 0u; hMJ = 0u; }
+        }
+        const unsigned seg_len = len - seg < 64u ? len - seg : 64u;
+        float xs = 0.0f;                                 // lane t keeps the margin of the segment's event t (the loss is summed from them by k_loss_margins: no double-precision code in this kernel)
+        // the two item rows of an event, gathered D events ahead of the arithmetic
+        auto gather = [&](float (&qi)[KR], float (&qj)[KR], unsigned t) {
+            const int ti = __builtin_amdgcn_readlane(hI, t), tj = __builtin_amdgcn_readlane(hJ, t);
+            const unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)(tj < 0 ? 0 : tj) * row_bytes;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { qi[r] = YUE_M_LOAD_I(rsQ, vo[r], oi); qj[r] = YUE_M_LOAD_J(rsQ, vo[r], oj); }
+        };
+        auto step = [&](const float (&qi)[KR], const float (&qj)[KR], unsigned t) {
+            const int tj = __builtin_amdgcn_readlane(hJ, t);
+            if (tj < 0) return;                          // (wave-uniform) the sampler gave up on the event: nothing is written
+            const int ti = __builtin_amdgcn_readlane(hI, t);
+            const uint32_t mi = (uint32_t)__builtin_amdgcn_readlane((int)hMI, t), mj = (uint32_t)__builtin_amdgcn_readlane((int)hMJ, t);
+            // per-lane partials in element order 64 r + l, r ascending (oracle/bpr_oracle.c: dot64)
+            float ai = 0.0f, aj = 0.0f;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { const float a1 = p[r] * qi[r]; ai = ai + a1; const float a2 = p[r] * qj[r]; aj = aj + a2; }
+            const float x = wave_sum(ai) - wave_sum(aj);                 // BPR.py:50, fp32 margin
+            const float c = FAST ? chain_coef_fast(x, lrf) : (float)(a.lr * (1.0 - chain_sigmoid(x)));
+            xs = (unsigned)lane == t ? x : xs;
+            const unsigned cli = meta_kind(mi), clj = meta_kind(mj);
+            const bool uniq_i = cli == kMetaUnique, uniq_j = clj == kMetaUnique;
+            const unsigned oi = (unsigned)ti * row_bytes, oj = (unsigned)tj * row_bytes;
+            // where the row's store goes: the row itself (only touch of the round) or the touch's staging row
+            const unsigned wi = uniq_i ? oi : stage0 + meta_slot(mi) * row_bytes;
+            const unsigned wj = uniq_j ? oj : stage0 + meta_slot(mj) * row_bytes;
+            Elem o[KR];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) { o[r] = bpr_elem(p[r], qi[r], qj[r], c, a.ru, a.ri); p[r] = o[r].p2; }   // BPR.py:51-57; the user row moves on
+            if (cli != kMetaHot) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_BSTORE(uniq_i ? o[r].qi2 : o[r].qi2 - qi[r], rsQ, vo[r], wi);
+            } else {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_M_HOT(o[r].qi2 - qi[r], rsdQ, vo[r], oi);
+            }
+            if (clj != kMetaHot) {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_BSTORE(uniq_j ? o[r].qj2 : o[r].qj2 - qj[r], rsQ, vo[r], wj);
+            } else {
+#pragma unroll
+                for (int r = 0; r < KR; ++r) YUE_M_HOT(o[r].qj2 - qj[r], rsdQ, vo[r], oj);
+            }
+        };
+        // a ring of D events: the rows of event t + D are requested when event t has been taken (lanes past the segment's end
+        // hold item 0 / no negative: their gathers read row 0 and are never looked at)
+        constexpr int D = 4;
+        float qi[D][KR], qj[D][KR];
+#pragma unroll
+        for (int s_ = 0; s_ < D; ++s_) gather(qi[s_], qj[s_], (unsigned)s_);
+        for (unsigned t = 0; t < seg_len; t += D) {
+#pragma unroll
+            for (int s_ = 0; s_ < D; ++s_) {
+                step(qi[s_], qj[s_], t + s_);
+                gather(qi[s_], qj[s_], (t + s_ + D) & 63u);
+            }
+        }
+        if ((unsigned)lane < seg_len) ra.margins[e0 + seg + lane] = xs;
+    }
+#pragma unroll
+    for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; if (e < k) prow[e] = p[r]; }
+}
+
+// sum over the events with a negative of -log(sigmoid(margin)) (BPR.py:58), double precision, into the loss slots
+__global__ void __launch_bounds__(256) k_loss_margins(const float *__restrict__ x, const int32_t *__restrict__ evj, int64_t E, double *nll_slots) {
+    double nl = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride)
+        if (evj[e] >= 0) nl += -log(chain_sigmoid(x[e]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nl += __shfl_xor(nl, off);
+    if ((threadIdx.x & 63) == 0 && nl != 0.0) atomicAdd(nll_slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kNllSlots - 1)), nl);
+}
+
 // Rewrites the contended item rows of one round from the pre-pass's fold list: row += the block of staged differences in
 // ticket order, or += the row of dQ (zeroed again) for a hot row.  A wave takes EPG consecutive list entries at a time
 // (rows of neighbouring items: their staging blocks lie behind each other), all loads before the first store.
