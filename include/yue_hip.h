@@ -184,16 +184,36 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *               list-update rate of the first 512 items; 2..64: that factor
  *   "fism_lds"   1 (default): yue_fism_rounds keeps a user's working rows in LDS when they fit (k_fism_round_lds); 0: always the
  *               form with working rows in global memory and host-built item lists
- *   "chain_waves" exact path: workgroups (of four waves) per CU of the dataflow launch, 1..8 (0 = default: 1)
- *   "chain_split" exact path: 1 = a run is walked by a PAIR of waves (k_bpr_chain2: one keeps the memory side, the other the
- *               dependency chain margin -> sigmoid -> user row; same results bit for bit; measured no faster: default 0)
+ *   "chain_waves" exact path: workgroups per CU of the dataflow launch, 1..8 (0 = default: 1; 2 with chain_xcd)
+ *   "chain_split" exact path: 1 = a run is walked by a GROUP of five waves (k_bpr_chain3: two keep the memory side -- headers,
+ *               prefetch rings, version checks, polling; even / odd triplets --, one the dependency chain margin -> sigmoid ->
+ *               user row, two store the updated item rows; hand-over through LDS; same results bit for bit); 0 = by one wave
+ *               (k_bpr_chain); -1 (default) = the group for streams of at least 16 triplets per run (BASELINE config 3: 940 ->
+ *               607 ms per epoch), one wave otherwise (short runs: the group's hand-offs and run starts cost more than they save)
+ *   "chain_fast"  exact path: 1 = the step's coefficient fp32(lr (1 - sigmoid(x))) in single precision and the margin as one
+ *               64-lane sum -- the reference's ORDER of updates, not its last bit: factors within BASELINE.json's 1e-5 of the
+ *               sequential loop (measured 3e-7..6e-7 on full configs 2, 3 and config 4's shard), 1.26e8 instead of 8.2e7 triplets/s
+ *               on config 3; 0 (default) = every operation as the reference rounds it (bit-equal to the oracle)
+ *   "chain_xcd"   exact path, wave group only: 1 = every working wave on ONE XCD (the other XCDs' workgroups leave at once), item rows
+ *               handed over through that XCD's L2 instead of the memory side; same results; default 0
+ *   "chain_ring"  exact path, wave group: triplets whose rows a loading wave keeps in flight, 8 (default) or 16 (k <= 128)
  *   "chain_spin"  exact path: polls a wave spends on one wait before it gives up with an error (0 = default: 2^22)
+ *   "round_user_seq" epoch path on one GPU: 1 (default) = a wave owns a user and applies the user's triplets in the reference's
+ *               order with P[u] in registers (k_round_u), only the item rows keep round semantics; 0 = user rows under round
+ *               semantics too (k_round_m, differences through dP: the form a communicator always runs)
+ *   "round_fast"  k_round_u: 1 (default) = the step's coefficient in single precision (as chain_fast); 0 = double precision
+ *   "comm_group_mb" communicator: MB of user-factor differences per ncclAllReduce (groups of user blocks), 1..4096, default 8
+ *               (what yue_epoch_plan announces); RCCL reaches its bus bandwidth at tens of MB
+ *   "round_cus_reserved" CUs the compute stream leaves free (the stream is re-created with a CU mask) for RCCL's kernels beside
+ *               round launches that otherwise fill the chip exactly; default 0
  * Behaviour switches:
  *   "epoch_exact" 1 = yue_bpr_epoch applies the epoch's triplets (device sampler's negatives) with the reference's exact
  *               sequential semantics (recommender/cf/BPR.py:42-58) instead of S-rounds: round_events is ignored, one GPU only
  *   "replay_levels" 1 = yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path, kept for
  *               comparison; same results)
  * Read-only (yue_get_option): "chain_last_runs" / "chain_last_waves" (runs walked / waves launched by the last exact launch),
+ *   "chain_last_us" (HIP-event time of that launch alone, microseconds), "round_last_user_seq" (1: the last epoch ran k_round_u),
+ *   "comm_last_compute_waits" (times the compute stream waited for the collective stream in the last epoch: 1),
  *   "replay_last_levels" (dependency levels of the last levelled replay), "scan_last_chunks" (filter + select launches of the
  *   last two-phase scan; 0: the fused kernel ran), "scan_last_settle" (1: most sampled users were settled against the catalogue's
  *   tail after the first chunk, the filter ran in the variant whose workgroups stop then), "round_last_stage_max" (largest staged block of the last epoch's pre-pass)

@@ -52,10 +52,12 @@ def main():
     for epoch in range(epochs):
         nll, sp, sq = dev.bpr_epoch(31, epoch, W, 0.05, 0.01, 0.01)
     stats = dev.comm_stats()
+    waits = dev.get_option('comm_last_compute_waits')      # the compute stream waits for the collective stream once per epoch: behind its last group
     tot = dev.allreduce_f64([nll])[0]
     P, Q = dev.get_factors()
     np.savez(os.path.join(out_dir, 'seam_rank%d.npz' % cp.rank), P=P, Q=Q, nll=nll, nll_total=tot, f32_calls=calls['f32'], elements=calls['elements'],
-             collectives=stats['collectives'], allreduce_bytes=stats['allreduce_bytes'], nranks=stats['nranks'], round_events=W)
+             collectives=stats['collectives'], allreduce_bytes=stats['allreduce_bytes'], nranks=stats['nranks'], round_events=W, compute_waits=waits,
+             group_mb=dev.get_option('comm_group_mb'))
     cp.barrier()
     dev.close()
     cp.close()

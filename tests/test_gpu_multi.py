@@ -105,6 +105,9 @@ def test_two_rank_epoch_on_one_gpu_through_the_test_seam(tmp_path, orc):
     for r in (r0, r1):
         assert int(r['collectives']) == len(plan['groups']) and int(r['nranks']) == 2
         assert float(r['allreduce_bytes']) == 4.0 * m * k and int(r['elements']) == epochs * m * k
+        # the groups' all-reduces and applies run on the second stream beside the next group's rounds: the compute stream waits
+        # for that stream exactly once per epoch, behind the last group (never between two groups)
+        assert int(r['compute_waits']) == 1 and int(r['group_mb']) == 8
 
 
 def test_four_rank_epoch_on_one_gpu_through_the_test_seam(tmp_path, orc):
@@ -188,3 +191,31 @@ def test_two_rank_product_epoch(tmp_path, orc):
     assert r0['nll_total'] == r1['nll_total'] and abs(r0['nll_total'] - (r0['nll'] + r1['nll'])) <= 1e-9 * abs(r0['nll_total'])
     P, Qs, _ = _two_shard_reference(orc, m, n, d, k, W, epochs)
     assert rel_err(r0['P'], P) < 1e-5 and rel_err(r0['Q'], Qs[0]) < 1e-5 and rel_err(r1['Q'], Qs[1]) < 1e-5
+
+
+def test_multi_gpu_knobs_do_not_change_the_epoch(orc):
+    """The two knobs kept for a real multi-GPU node -- comm_group_mb (MB of user-factor differences per all-reduce) and
+    round_cus_reserved (CUs the compute stream leaves to RCCL's kernels: the stream is re-created with a CU mask) -- on a
+    1-rank communicator: same factors as with the defaults, more / fewer collectives as asked."""
+    from yue_amd._shim import Device, comm_unique_id
+    from yue_amd import synth
+    m, n, d, k, W = 40000, 3000, 10, 128, 16384
+    data = synth.make_arrays(m, n, d, seed=3)
+    P0, Q0 = synth.init_factors(m, n, k, 4)
+    res = []
+    for group_mb, reserved in ((8, 0), (2, 0), (64, 16)):
+        dev = Device(0, raise_errors=True)
+        try:
+            dev.set_option('comm_group_mb', group_mb)
+            dev.set_option('round_cus_reserved', reserved)
+            dev.set_factors(P0, Q0)
+            dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+            dev.comm_init(comm_unique_id(), 0, 1)
+            nll = dev.bpr_epoch(7, 0, W, 0.02, 0.01, 0.01)[0]
+            res.append((nll, dev.comm_stats()['collectives']) + dev.get_factors())
+            assert dev.get_option('comm_last_compute_waits') == 1
+        finally:
+            dev.close()
+    assert res[1][1] > res[0][1] > res[2][1] >= 1                  # 20 MB of user rows: 2 MB groups > 8 MB groups > one group
+    for r in res[1:]:
+        assert abs(r[0] - res[0][0]) <= 1e-12 * abs(res[0][0]) and np.array_equal(r[2], res[0][2]) and rel_err(r[3], res[0][3]) < 1e-6

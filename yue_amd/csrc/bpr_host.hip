@@ -654,6 +654,9 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
     // one GPU: nobody waits for the user rows of a group (a user's events all lie in one round, P[u] is not read again this epoch),
     // so the differences are applied once behind the last round instead of group by group between the rounds
     if (!yue_host::on_communicator(c)) group = std::max<int64_t>(1, (c->m + ub - 1) / ub);
+    // communicator: the size of one all-reduce is a knob (option comm_group_mb; a user's dP is not needed before the next epoch,
+    // so groups may be large -- RCCL reaches its bus bandwidth at tens of MB)
+    else group = std::max<int64_t>(1, ((int64_t)c->opt_comm_group_mb << 20) / std::max<int64_t>(1, ub * c->k * 4));
     std::vector<int64_t> ublock;
     for (int64_t u0 = 0; u0 < c->m; u0 += ub) { ublock.push_back(u0); bounds.push_back(c->h_ev_ptr[(size_t)u0]); }
     ublock.push_back(c->m); bounds.push_back(E);
@@ -702,7 +705,8 @@ int yue_bpr_epoch(yue_ctx *c, uint64_t seed, uint32_t epoch, int64_t round_event
         HIPCHK(hipEventRecord(c->ev_t_comm, c->comm_stream));
     }
     HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));      // the ONLY wait of the compute stream for the collective stream in an epoch
+    c->comm_compute_waits = 1;
     HIPCHK(hipGetLastError());
     if ((rc = sumsq_async(c))) return rc;
     if ((rc = read_scalars(c, nll_out, sumsqP_out, sumsqQ_out))) return rc;
@@ -796,6 +800,9 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "round_stage") *value = c->opt_round_stage;
     else if (key == "round_last_stage_max") *value = c->last_stage_max;
     else if (key == "round_meta") *value = c->opt_round_meta;
+    else if (key == "comm_group_mb") *value = c->opt_comm_group_mb;
+    else if (key == "round_cus_reserved") *value = c->opt_round_cus_reserved;
+    else if (key == "comm_last_compute_waits") *value = c->comm_compute_waits;
     else if (key == "round_user_seq") *value = c->opt_round_user_seq;
     else if (key == "round_fast") *value = c->opt_round_fast;
     else if (key == "round_last_user_seq") *value = c->last_round_user_seq;
@@ -834,6 +841,27 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
         c->opt_round_stage = (int)value; return YUE_OK;
     }
     if (key == "round_meta") { c->opt_round_meta = value != 0; return YUE_OK; }
+    if (key == "comm_group_mb") { if (value < 1 || value > 4096) return fail(YUE_ERR_ARG, "yue_set_option: comm_group_mb must be 1..4096"); c->opt_comm_group_mb = (int)value; return YUE_OK; }
+    if (key == "round_cus_reserved") {
+        // the compute stream is re-created with a CU mask that leaves the LAST `value` CUs of the device free: RCCL's kernels
+        // (collective stream, no mask) find room beside round launches that would otherwise fill the chip exactly
+        int cus = 0;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (value < 0 || value >= cus) return fail(YUE_ERR_ARG, "yue_set_option: round_cus_reserved must be 0 .. CUs - 1");
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipStream_t fresh = nullptr;
+        if (value == 0) HIPCHK(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+        else {
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (int cu = 0; cu < cus - (int)value; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+            HIPCHK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)mask.size(), mask.data()));
+        }
+        (void)hipStreamDestroy(c->stream);
+        c->stream = fresh;
+        c->opt_round_cus_reserved = (int)value;
+        return YUE_OK;
+    }
     if (key == "round_user_seq") { c->opt_round_user_seq = value != 0; return YUE_OK; }
     if (key == "round_fast") { c->opt_round_fast = value != 0; return YUE_OK; }
     if (key == "epoch_exact") { c->opt_epoch_exact = value != 0; return YUE_OK; }

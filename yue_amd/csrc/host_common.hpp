@@ -113,6 +113,9 @@ struct yue_ctx {
     int opt_round_user_seq = 1;          // epoch path on one GPU: 1 = a wave owns a user and walks the user's events in order (k_round_u); 0 = user rows with round semantics (k_round_m + dP)
     int opt_round_fast = 1;              // k_round_u: the step's coefficient in single precision (0: the reference's double-precision sigmoid)
     int last_round_user_seq = 0;         // the last epoch ran k_round_u (read-only option round_last_user_seq)
+    int opt_comm_group_mb = 8;           // communicator: user-factor differences per all-reduce (groups of user blocks), MB (8 = what yue_epoch_plan announces; RCCL reaches its bus bandwidth at tens of MB: try 32..64 on a real node)
+    int opt_round_cus_reserved = 0;      // CUs the compute stream leaves free (CU mask of the stream) for RCCL's kernels beside the round launches
+    int64_t comm_compute_waits = 0;      // times the compute stream waited for the collective stream in the last epoch (read-only option comm_last_compute_waits)
     int opt_round_meta = 1;              // 0: the epoch path counts touches inside the round launches (k_round) as the explicit-rounds path does
     // kernel timing
     int timing_stride = 0;

@@ -168,6 +168,12 @@ class ControlPlane(object):
         out = self._scatter_same(struct.pack('<d', max(struct.unpack('<d', p)[0] for p in parts)) if self.rank == 0 else None)
         return struct.unpack('<d', out)[0]
 
+    def gather_floats(self, x):
+        """every rank's value, in rank order, on every rank (bench.py: per-rank step times beside their maximum)"""
+        parts = self._gather(struct.pack('<d', float(x)))
+        out = self._scatter_same(b''.join(parts) if self.rank == 0 else None)
+        return list(struct.unpack('<%dd' % (len(out) // 8), out))
+
     def allreduce_sum(self, array):
         """In-place float32/float64 numpy sum over ranks, added in rank order (CPU; the executable spec in tests)."""
         if self.world == 1:
