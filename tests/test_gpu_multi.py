@@ -218,4 +218,5 @@ def test_multi_gpu_knobs_do_not_change_the_epoch(orc):
             dev.close()
     assert res[1][1] > res[0][1] > res[2][1] >= 1                  # 20 MB of user rows: 2 MB groups > 8 MB groups > one group
     for r in res[1:]:
-        assert abs(r[0] - res[0][0]) <= 1e-12 * abs(res[0][0]) and np.array_equal(r[2], res[0][2]) and rel_err(r[3], res[0][3]) < 1e-6
+        # (the same arithmetic; only the order of float-atomic sums and of the loss partials differs from run to run)
+        assert abs(r[0] - res[0][0]) <= 1e-9 * abs(res[0][0]) and rel_err(r[2], res[0][2]) < 1e-6 and rel_err(r[3], res[0][3]) < 1e-6
