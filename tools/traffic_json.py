@@ -37,17 +37,19 @@ def main():
     fetch_path, write_path, workload, round_events = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     taken = sys.argv[5] if len(sys.argv) > 5 else 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum, separate passes'
     f, w = parse(fetch_path), parse(write_path)
-    km, kf = pick(f, 'k_round_m<'), pick(f, 'k_round_fold<')
-    fetch = {'k_round_m': f[km]['FETCH_SIZE'][0], 'k_round_fold': f[kf]['FETCH_SIZE'][0]}
-    write = {'k_round_m': w[pick(w, 'k_round_m<')]['WRITE_SIZE'][0], 'k_round_fold': w[pick(w, 'k_round_fold<')]['WRITE_SIZE'][0]}
-    atomics = w[pick(w, 'k_round_m<')].get('TCC_EA0_ATOMIC_sum', (0.0, 0))[0]
+    # the round's update launch: k_round_u (round 4: sequential user rows, one GPU) where the pass ran it, else k_round_m
+    upd = 'k_round_u' if any('k_round_u<' in name for name in f) else 'k_round_m'
+    km, kf = pick(f, upd + '<'), pick(f, 'k_round_fold<')
+    fetch = {upd: f[km]['FETCH_SIZE'][0], 'k_round_fold': f[kf]['FETCH_SIZE'][0]}
+    write = {upd: w[pick(w, upd + '<')]['WRITE_SIZE'][0], 'k_round_fold': w[pick(w, 'k_round_fold<')]['WRITE_SIZE'][0]}
+    atomics = w[pick(w, upd + '<')].get('TCC_EA0_ATOMIC_sum', (0.0, 0))[0]
     # calibration: k_sumsq reads the user factors and the item factors once each (two launches per epoch, averaged here)
     cal_bytes = float(os.environ.get('CALIBRATION_BYTES', (1000000 + 200000) * 128 * 4 / 2))
     cal_kib = f[pick(f, 'k_sumsq')]['FETCH_SIZE'][0]
     corr = cal_bytes / 1024.0 / cal_kib
-    traffic = (fetch['k_round_m'] + fetch['k_round_fold']) * 1024.0 * round(corr) + (write['k_round_m'] + write['k_round_fold']) * 1024.0
+    traffic = (fetch[upd] + fetch['k_round_fold']) * 1024.0 * round(corr) + (write[upd] + write['k_round_fold']) * 1024.0
     print(json.dumps({
-        '_comment': 'HBM-side traffic of one S-round of the epoch path = its update launch (k_round_m) + its fold launch (k_round_fold), '
+        '_comment': 'HBM-side traffic of one S-round of the epoch path = its update launch (' + upd + ') + its fold launch (k_round_fold), '
                     'from rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary` '
                     '(tools/profile_round.sh -> tools/traffic_json.py). FETCH_SIZE is in KiB and reads 1/2 of the bytes on gfx950 for '
                     'these 4-byte-per-lane loads (calibrated in the same pass on k_sumsq: %.1f KiB reported for %.0f KiB read -> x%.3f, '
