@@ -794,6 +794,7 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "scan_two_phase") *value = c->opt_scan_two_phase;
     else if (key == "fism_lds") *value = c->opt_fism_lds;
     else if (key == "scan_growth") *value = c->opt_scan_growth;
+    else if (key == "scan_filter_ub") *value = c->opt_scan_filter_ub;
     else if (key == "scan_last_chunks") *value = c->scan_chunks;
     else if (key == "scan_last_settle") *value = c->scan_settle;
     else if (key == "topn_true") *value = c->opt_topn_true;
@@ -835,6 +836,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "scan_two_phase") { c->opt_scan_two_phase = value != 0; return YUE_OK; }
     if (key == "fism_lds") { c->opt_fism_lds = value != 0; return YUE_OK; }
+    if (key == "scan_filter_ub") { if (value != 1 && value != 2) return fail(YUE_ERR_ARG, "yue_set_option: scan_filter_ub must be 1 or 2"); c->opt_scan_filter_ub = (int)value; return YUE_OK; }
     if (key == "scan_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(YUE_ERR_ARG, "yue_set_option: scan_growth must be 0 (automatic) or 2..64"); c->opt_scan_growth = (int)value; return YUE_OK; }
     if (key == "round_stage") {
         if (value < 0 || value > (int64_t)yue::kMetaStageMax) return fail(YUE_ERR_ARG, "yue_set_option: round_stage must be 0, 1 or 2..64");

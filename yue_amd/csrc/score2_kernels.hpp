@@ -178,11 +178,27 @@ __global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
 #pragma unroll
                     for (int z = 0; z < 16; ++z) acc[b][z] = 0.0f;
                 const __bf16 *irow = tbb + (q * kScanTile + r) * LDB + 8 * h;
+                if (UB == 1) {
 #pragma unroll
-                for (int s = 0; s < K16; ++s) {
-                    const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s);
+                    for (int s = 0; s < K16; ++s) {
+                        const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[0][s], acc[0], 0, 0, 0);
+                    }
+                } else {
+                    // the item fragments through a ring of three registers (ds_read_b128 two k-steps ahead of its UB MFMAs): left to
+                    // itself the compiler keeps all K16 fragments live beside af[UB][K16] and acc[UB] -- 162 VGPRs, one workgroup
+                    // fewer per CU (round 3).  The empty statements pin the order: a read may not move above the one in front of it.
+                    bf16x8 ring[3];
+                    ring[0] = *reinterpret_cast<const bf16x8 *>(irow);
+                    if (K16 > 1) ring[1] = *reinterpret_cast<const bf16x8 *>(irow + 16);
 #pragma unroll
-                    for (int b = 0; b < UB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[b][s], acc[b], 0, 0, 0);
+                    for (int s = 0; s < K16; ++s) {
+                        asm volatile("" ::: "memory");
+                        if (s + 2 < K16) ring[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(irow + 16 * (s + 2));
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int b = 0; b < UB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3], af[b][s], acc[b], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < UB; ++b) {
