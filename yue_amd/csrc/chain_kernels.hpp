@@ -71,13 +71,22 @@ struct ChainArgs {
 #define YUE_CS(...)
 #endif
 
-// Rows (fp32, k elements) -> granule rows of 64 * KR granules {element e, version 0} (value 0 for e >= k), and back.
+// Rows (fp32, k elements) -> granule rows of 64 * KR granules {element, version 0} (value 0 for elements >= k), and back.
+// A lane holds elements 64 r + l (r < KR) of a row, as everywhere in the training kernels.  For k > 64 its granules of an
+// even / odd pair of r lie NEXT TO EACH OTHER in the granule row (slot (r / 2) * 128 + 2 l + (r & 1)), so that ONE 16-byte
+// memory instruction moves two granules of a lane -- each still validated by its own version: a 16-byte access that tears
+// into its 8-byte halves (observed, round 3) leaves one half stale and recognisable, never a wrong value.
 __host__ __device__ inline int chain_granules_per_row(int k) { return k <= 64 ? 64 : k <= 128 ? 128 : 256; }
+__host__ __device__ inline int chain_element_of_slot(int gpr, int t) {      // which element of the row granule slot t holds
+    if (gpr == 64) return t;
+    const int q = t >> 7, l = (t & 127) >> 1, r = 2 * q + (t & 1);
+    return 64 * r + l;
+}
 __global__ void __launch_bounds__(256) k_chain_pack(const float *X, unsigned *Xv, int64_t rows, int k) {
     const int gpr = chain_granules_per_row(k);
     const int64_t total = rows * gpr, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int64_t row = t / gpr; const int e = (int)(t - row * gpr);
+        const int64_t row = t / gpr; const int e = chain_element_of_slot(gpr, (int)(t - row * gpr));
         u32x2 g; g.x = e < k ? __builtin_bit_cast(unsigned, X[row * k + e]) : 0u; g.y = 0u;
         reinterpret_cast<u32x2 *>(Xv)[t] = g;
     }
@@ -86,7 +95,7 @@ __global__ void __launch_bounds__(256) k_chain_unpack(const unsigned *Xv, float 
     const int gpr = chain_granules_per_row(k);
     const int64_t total = rows * gpr, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int64_t row = t / gpr; const int e = (int)(t - row * gpr);
+        const int64_t row = t / gpr; const int e = chain_element_of_slot(gpr, (int)(t - row * gpr));
         if (e < k) X[row * k + e] = __builtin_bit_cast(float, Xv[2 * t]);
     }
 }
@@ -162,16 +171,45 @@ __device__ __forceinline__ void vmem_sgpr_guard(unsigned &s0, unsigned &s1) { as
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void vmem_sgpr_guard(i32x4 &rs) { asm volatile("s_nop 4" : "+s"(rs)); }
 
-struct Gran {
-    typedef u32x2 reg; typedef float val;
-    static __device__ __forceinline__ void load(reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(d) : "v"(vo), "s"(rs), "s"(so) : "memory"); }
-    static __device__ __forceinline__ void store(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory"); }
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+// The granules of ONE row in a lane: KR = 1 -- one granule, 8-byte instructions; KR >= 2 -- KR / 2 pairs {value, version, value,
+// version} of elements 64 (2 q) + l and 64 (2 q + 1) + l, 16-byte instructions.
+template <int KR>
+struct GranRow {
+    static constexpr int NL = KR == 1 ? 1 : KR / 2;                      // memory instructions per row and lane
+    typedef typename std::conditional<KR == 1, u32x2, u32x4v>::type reg;
+    static __device__ __forceinline__ unsigned voffset(int q, int lane) { return KR == 1 ? (unsigned)lane * 8u : (unsigned)q * 1024u + (unsigned)lane * 16u; }
+    static __device__ __forceinline__ void load(reg &d, unsigned vo, const i32x4 &rs, unsigned so) {
+        if constexpr (KR == 1) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1" : "=v"(d) : "v"(vo), "s"(rs), "s"(so) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(d) : "v"(vo), "s"(rs), "s"(so) : "memory");
+    }
+    static __device__ __forceinline__ void store(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) {
+        if constexpr (KR == 1) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
+        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
+    }
     // the same store left in the XCD's L2 (no write-through): only for a launch whose waves ALL sit behind one L2 (k_bpr_chain3<.., ONE_XCD>)
-    static __device__ __forceinline__ void store_l2(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) { asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory"); }
-    static __device__ __forceinline__ val value(const reg &d) { return __builtin_bit_cast(float, d.x); }
-    static __device__ __forceinline__ bool is(const reg &d, unsigned want) { return d.y == want; }
-    static __device__ __forceinline__ unsigned version(const reg &d) { return d.y; }
-    static __device__ __forceinline__ reg make(val v, unsigned ver) { reg d; d.x = __builtin_bit_cast(unsigned, v); d.y = ver; return d; }
+    static __device__ __forceinline__ void store_l2(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) {
+        if constexpr (KR == 1) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
+        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
+    }
+    // element r (0 .. KR - 1) of the row
+    static __device__ __forceinline__ float value(const reg (&g)[NL], int r) {
+        if constexpr (KR == 1) return __builtin_bit_cast(float, g[0].x);
+        else return __builtin_bit_cast(float, (r & 1) ? g[r >> 1].z : g[r >> 1].x);
+    }
+    // 0 iff every granule of the lane carries version `want`
+    static __device__ __forceinline__ unsigned bad(const reg (&g)[NL], unsigned want) {
+        unsigned b = 0u;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) { b |= g[q].y ^ want; if constexpr (KR != 1) b |= g[q].w ^ want; }
+        return b;
+    }
+    static __device__ __forceinline__ unsigned version0(const reg &d) { return d.y; }
+    static __device__ __forceinline__ void set(reg (&g)[NL], int r, float v, unsigned ver) {
+        if constexpr (KR == 1) { g[0].x = __builtin_bit_cast(unsigned, v); g[0].y = ver; }
+        else if (r & 1) { g[r >> 1].z = __builtin_bit_cast(unsigned, v); g[r >> 1].w = ver; }
+        else { g[r >> 1].x = __builtin_bit_cast(unsigned, v); g[r >> 1].y = ver; }
+    }
 };
 
 template <int GR, int N, typename R>
@@ -191,16 +229,16 @@ __device__ __forceinline__ void row_wait_all(R (&g)[GR]) {
 template <int KR, bool PVER, int G, bool FAST>
 __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                    const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
-    constexpr int GR = KR, GB = 8;                       // granules per lane and row, granule bytes
-    typedef Gran GT;
+    typedef GranRow<KR> GT;
+    constexpr int GR = GT::NL, GB = 8;                   // memory instructions per row and lane, granule bytes
     typedef typename GT::reg greg;
-    typedef typename GT::val gval;
+    typedef float gval;
     const int lane = threadIdx.x & 63;
     const unsigned k = (unsigned)a.k;
-    const unsigned row_bytes = (unsigned)GR * 64u * GB;  // granule rows
+    const unsigned row_bytes = (unsigned)KR * 64u * GB;  // granule rows
     unsigned vo[GR];
 #pragma unroll
-    for (int g = 0; g < GR; ++g) vo[g] = (64u * g + lane) * GB;      // (elements beyond k are zero-valued granules of the copy: no masking here)
+    for (int g = 0; g < GR; ++g) vo[g] = GT::voffset(g, lane);       // (elements beyond k are zero-valued granules of the copy: no masking here)
     const unsigned v_oob = kOobOffset;
     const uint64_t qbytes = (uint64_t)a.n * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
@@ -214,10 +252,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
     YUE_CS(unsigned long long cs_fast = 0, cs_nfast = 0, cs_slow = 0, cs_nslow = 0, cs_run = 0, cs_nrun = 0;)
 
     auto all_mine = [&](uint32_t want, const greg (&g)[GR]) -> bool {
-        bool mine = true;
-#pragma unroll
-        for (int q = 0; q < GR; ++q) mine = mine && GT::is(g[q], want);
-        return __builtin_amdgcn_ballot_w64(!mine) == 0ull;
+        return __builtin_amdgcn_ballot_w64(GT::bad(g, want) != 0u) == 0ull;
     };
     // Slow path of a wait: polls until all granules of the row carry `want`; false if the wave gave up (status set).
     // Far from its turn (the row's version says how far) a wave sleeps in proportion and polls ONE granule; only the next
@@ -228,7 +263,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
         bool fresh = false;                                      // g is the prefetch of several triplets ago: its version says nothing yet
         for (;;) {
             // how far away is my turn?  (granule 0 of the row; a row in the middle of a rewrite reads as distance 0)
-            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(g[0])) : 0u;
+            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version0(g[0])) : 0u;
             fresh = true;
             while ((int32_t)dist > 1) {
                 const uint32_t naps = dist < 16u ? dist : 16u;      // ~0.5 us per touch in front of me, capped
@@ -237,7 +272,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                 const unsigned v1 = lane == 0 ? 0u : kOobOffset;
                 GT::load(one[0], v1, rs, so);
                 row_wait_all<1>(one);
-                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(one[0]));
+                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version0(one[0]));
                 if (++polls > a.spin_limit || (int32_t)dist < 0) break;
                 if ((polls & 63u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             }
@@ -266,7 +301,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
         const int64_t u = a.run_u ? (int64_t)a.run_u[run] : (int64_t)run;
         const unsigned len = (unsigned)(e1 - e0 < 0x7fffffff ? e1 - e0 : 0x7fffffff);
 
-        gval p[GR];
+        gval p[KR];
         uint32_t pver = 0u;
         i32x4 rp;
         if (PVER) {
@@ -282,11 +317,11 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
             row_wait_all<GR>(g);
             if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) { dead = true; break; }
 #pragma unroll
-            for (int q = 0; q < GR; ++q) p[q] = GT::value(g[q]);
+            for (int r = 0; r < KR; ++r) p[r] = GT::value(g, r);
         } else {
             const float *prow = a.P + (uint64_t)u * k;
 #pragma unroll
-            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; p[q] = e < k ? prow[e] : 0.0f; }
+            for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; p[r] = e < k ? prow[e] : 0.0f; }
         }
 
         // The run in segments of 64 triplets (one segment for the usual run): the segment's headers sit in the lanes of four
@@ -315,7 +350,7 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
             // (empty statements that read what the compiler's own loads above produced: the compiler places ITS waits for them
             // here, not in front of every step's arithmetic, where they would drain the ring)
 #pragma unroll
-            for (int q = 0; q < GR; ++q) asm volatile("" : "+v"(p[q]));
+            for (int r = 0; r < KR; ++r) asm volatile("" : "+v"(p[r]));
             asm volatile("" : "+v"(hAi), "+v"(hAj), "+v"(hAwi), "+v"(hAwj));
 #pragma unroll
             for (int s = 0; s < G; ++s) fill(s, __builtin_amdgcn_readlane(hAi, s), __builtin_amdgcn_readlane(hAj, s));
@@ -339,26 +374,27 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                         if (ok && !all_mine(wi, gi[s])) { ok = acquire_slow(rq, oi, wi, gi[s]); YUE_CS(cs_waited = true;) }
                         if (!ok) dead = true;
                         else {
-                            gval qi[GR], qj[GR];
+                            gval qi[KR], qj[KR];
 #pragma unroll
-                            for (int q = 0; q < GR; ++q) { qi[q] = GT::value(gi[s][q]); qj[q] = GT::value(gj[s][q]); }
+                            for (int r = 0; r < KR; ++r) { qi[r] = GT::value(gi[s], r); qj[r] = GT::value(gj[s], r); }
                             float x;
                             if (FAST) {
                                 // option chain_fast (within 1e-5, not bit-equal): one 64-lane sum of p . (qi - qj)
                                 float acc = 0.0f;
 #pragma unroll
-                                for (int q = 0; q < GR; ++q) { const gval dq = qi[q] - qj[q]; acc = q == 0 ? p[0] * dq : __builtin_fmaf(p[q], dq, acc); }
+                                for (int q = 0; q < KR; ++q) { const gval dq = qi[q] - qj[q]; acc = q == 0 ? p[0] * dq : __builtin_fmaf(p[q], dq, acc); }
                                 x = wave_sum_any(acc);
                             } else {
                                 // per-lane partials in element order 64 r + l, r ascending (oracle/bpr_oracle.c: dot64)
                                 float ai = 0.0f, aj = 0.0f;
 #pragma unroll
-                                for (int q = 0; q < GR; ++q) { const gval mi = p[q] * qi[q], mj = p[q] * qj[q]; ai = ai + mi; aj = aj + mj; }
+                                for (int q = 0; q < KR; ++q) { const gval mi = p[q] * qi[q], mj = p[q] * qj[q]; ai = ai + mi; aj = aj + mj; }
                                 x = wave_sum(ai) - wave_sum(aj);                     // BPR.py:50, fp32 margin
                             }
                             const float c = FAST ? chain_coef_fast(x, (float)a.lr) : (float)(a.lr * (1.0 - chain_sigmoid(x)));   // qmath.py:115-116
+                            greg oi_[GR], oj_[GR];
 #pragma unroll
-                            for (int q = 0; q < GR; ++q) {
+                            for (int q = 0; q < KR; ++q) {
                                 // BPR.py:51-57 (as bpr_elem)
                                 const gval d = qi[q] - qj[q];
                                 const gval td = c * d;
@@ -367,8 +403,13 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                                 const gval qi1 = qi[q] + tq, qj1 = qj[q] - tq;
                                 const gval rpp = a.ru * p1, ra = a.ri * qi1, rb = a.ri * qj1;
                                 p[q] = p1 - rpp;
-                                GT::store(GT::make(qi1 - ra, wi + 1u), vo[q], rq, oi);   // the positive's row first: the hotter of the two
-                                GT::store(GT::make(qj1 - rb, wj + 1u), vo[q], rq, oj);
+                                GT::set(oi_, q, qi1 - ra, wi + 1u);
+                                GT::set(oj_, q, qj1 - rb, wj + 1u);
+                            }
+#pragma unroll
+                            for (int q = 0; q < GR; ++q) {
+                                GT::store(oi_[q], vo[q], rq, oi);                    // the positive's row first: the hotter of the two
+                                GT::store(oj_[q], vo[q], rq, oj);
                             }
                             xs = (unsigned)lane == nsv ? x : xs;
                             if (++nsv == 64u) flush_logs();
@@ -376,9 +417,11 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
                         }
                     }
                     if (!done) {                                     // no event in this slot: the step's stores as dummies
-                        greg z = GT::make(0.0f, 0u);
+                        greg z[GR];
 #pragma unroll
-                        for (int q = 0; q < GR; ++q) { GT::store(z, v_oob, rq, 0u); GT::store(z, v_oob, rq, 0u); }
+                        for (int r = 0; r < KR; ++r) GT::set(z, r, 0.0f, 0u);
+#pragma unroll
+                        for (int q = 0; q < GR; ++q) { GT::store(z[q], v_oob, rq, 0u); GT::store(z[q], v_oob, rq, 0u); }
                     }
                     // refill with the same slot of the next group (dummies past the segment's last group)
                     fill(s, more ? __builtin_amdgcn_readlane(hAi, (ol + G + s) & 63u) : 0, more ? __builtin_amdgcn_readlane(hAj, (ol + G + s) & 63u) : -1);
@@ -390,12 +433,15 @@ __global__ void __launch_bounds__(256) k_bpr_chain(ChainArgs a, const int32_t *_
         if (dead) break;
 
         if (PVER) {
+            greg pg[GR];
 #pragma unroll
-            for (int q = 0; q < GR; ++q) GT::store(GT::make(p[q], pver + 1u), vo[q], rp, 0u);
+            for (int r = 0; r < KR; ++r) GT::set(pg, r, p[r], pver + 1u);
+#pragma unroll
+            for (int q = 0; q < GR; ++q) GT::store(pg[q], vo[q], rp, 0u);
         } else {
             float *prow = a.P + (uint64_t)u * k;
 #pragma unroll
-            for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; if (e < k) prow[e] = p[q]; }
+            for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; if (e < k) prow[e] = p[r]; }
         }
         YUE_CS(cs_run += __builtin_readcyclecounter() - cs_r0 - cs_steps; ++cs_nrun;)
     }
@@ -470,8 +516,8 @@ template <int L> __device__ __forceinline__ unsigned write_lane(unsigned v, unsi
 template <int KR, bool PVER, int G, bool FAST, bool ONE_XCD>
 __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *__restrict__ evi, const int32_t *__restrict__ evj,
                                                     const uint32_t *__restrict__ ordi, const uint32_t *__restrict__ ordj) {
-    constexpr int GR = KR, GB = 8;
-    typedef Gran GT;
+    typedef GranRow<KR> GT;
+    constexpr int GR = GT::NL, GB = 8;                   // memory instructions per row and lane, granule bytes
     typedef typename GT::reg greg;
     typedef TrioBox<KR> Box;
     __shared__ Box box;
@@ -487,7 +533,7 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
     if (threadIdx.x < 128) box.sdone[threadIdx.x >> 6][threadIdx.x & 63] = 0u;
     __syncthreads();
     const unsigned k = (unsigned)a.k;
-    const unsigned row_bytes = (unsigned)GR * 64u * GB;  // granule rows
+    const unsigned row_bytes = (unsigned)KR * 64u * GB;  // granule rows
     // every wait of waves C and S ends when wave L publishes; wave L's own waits are bounded by the spin limit.  The bound
     // below only guards against a protocol error: a wave that has slept this often sets the status word and leaves.
     constexpr uint32_t kIdleLimit = 1u << 30;
@@ -588,7 +634,7 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
 
     unsigned vo[GR];
 #pragma unroll
-    for (int g = 0; g < GR; ++g) vo[g] = (64u * g + lane) * GB;      // (elements beyond k are zero-valued granules of the copy: no masking here)
+    for (int g = 0; g < GR; ++g) vo[g] = GT::voffset(g, lane);       // (elements beyond k are zero-valued granules of the copy: no masking here)
     const uint64_t qbytes = (uint64_t)a.n * row_bytes;
     const int qrec = (int)(qbytes < 0x7fffffffull ? qbytes : 0x7fffffffull);
     i32x4 rq;                                            // buffer descriptor of Qv as plain words, for the assembly operands
@@ -617,12 +663,15 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
         auto store_user_row = [&]() {
             if (PVER) {
                 const i32x4 rp = user_rsrc(u_run);
+                greg pg[GR];
 #pragma unroll
-                for (int q = 0; q < GR; ++q) { if (ONE_XCD) GT::store_l2(GT::make(p[q], pver1), vo[q], rp, 0u); else GT::store(GT::make(p[q], pver1), vo[q], rp, 0u); }
+                for (int r = 0; r < KR; ++r) GT::set(pg, r, p[r], pver1);
+#pragma unroll
+                for (int q = 0; q < GR; ++q) { if (ONE_XCD) GT::store_l2(pg[q], vo[q], rp, 0u); else GT::store(pg[q], vo[q], rp, 0u); }
             } else {
                 float *prow = a.P + (uint64_t)u_run * k;
 #pragma unroll
-                for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; if (e < k) prow[e] = p[q]; }
+                for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; if (e < k) prow[e] = p[r]; }
             }
         };
         // One packet at a time, but never one LDS round trip after the other: the next packet's tag, rows, header and wave C's
@@ -658,15 +707,19 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
                 unsigned orow = (unsigned)(neg ? __builtin_amdgcn_readlane((int)mv, 1) : __builtin_amdgcn_readlane((int)mv, 0)) * row_bytes;
                 const uint32_t w1 = (uint32_t)(neg ? __builtin_amdgcn_readlane((int)mv, 3) : __builtin_amdgcn_readlane((int)mv, 2)) + 1u;
                 vmem_sgpr_guard(orow);
+                greg og[GR];
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    Elem o;
+                    if (YUE_ABL & 32) { o.p2 = p[r]; o.qi2 = d[r]; o.qj2 = c; } else o = bpr_elem(p[r], d[r], d[KR + r], c, a.ru, a.ri);    // BPR.py:51-57
+                    p[r] = o.p2;
+                    GT::set(og, r, neg ? o.qj2 : o.qi2, w1);
+                }
 #pragma unroll
                 for (int q = 0; q < GR; ++q) {
-                    Elem o;
-                    if (YUE_ABL & 32) { o.p2 = p[q]; o.qi2 = d[q]; o.qj2 = c; } else o = bpr_elem(p[q], d[q], d[KR + q], c, a.ru, a.ri);    // BPR.py:51-57
-                    p[q] = o.p2;
-                    const float mine = neg ? o.qj2 : o.qi2;
-                    if (YUE_ABL & (16 | 4)) { asm volatile("" :: "v"(mine), "s"(orow)); }
-                    else if (ONE_XCD) GT::store_l2(GT::make(mine, w1), vo[q], rq, orow);
-                    else GT::store(GT::make(mine, w1), vo[q], rq, orow);
+                    if (YUE_ABL & (16 | 4)) { asm volatile("" :: "v"(og[q]), "s"(orow)); }
+                    else if (ONE_XCD) GT::store_l2(og[q], vo[q], rq, orow);
+                    else GT::store(og[q], vo[q], rq, orow);
                 }
                 YUE_CS(++cs_sn;)
             }
@@ -709,17 +762,14 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
     YUE_CS(unsigned long long cs_lfast = 0, cs_lnfast = 0, cs_lring = 0;)
 
     auto all_mine = [&](uint32_t want, const greg (&g)[GR]) -> bool {
-        unsigned bad = 0u;
-#pragma unroll
-        for (int q = 0; q < GR; ++q) bad |= GT::version(g[q]) ^ want;
-        return all_lanes(bad == 0u);
+        return all_lanes(GT::bad(g, want) == 0u);
     };
     // Slow path of a wait, as in k_bpr_chain: far from its turn a wave sleeps in proportion and polls ONE granule.
     auto acquire_slow = [&](const i32x4 &rs, unsigned so, uint32_t want, greg (&g)[GR]) -> bool {
         uint32_t polls = 0;
         bool fresh = false;
         for (;;) {
-            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(g[0])) : 0u;
+            uint32_t dist = fresh ? want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version0(g[0])) : 0u;
             fresh = true;
             while ((int32_t)dist > 1) {
                 const uint32_t naps = dist < 16u ? dist : 16u;
@@ -728,7 +778,7 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
                 const unsigned v1 = lane == 0 ? 0u : kOobOffset;
                 GT::load(one[0], v1, rs, so);
                 row_wait_all<1>(one);
-                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version(one[0]));
+                dist = want - (uint32_t)__builtin_amdgcn_readfirstlane((int)GT::version0(one[0]));
                 if (++polls > a.spin_limit || (int32_t)dist < 0) break;
                 if ((polls & 63u) == 0u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             }
@@ -799,11 +849,11 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
                 row_wait_all<GR>(g);
                 if (!all_mine(pver, g) && !acquire_slow(rp, 0u, pver, g)) goto bail;
 #pragma unroll
-                for (int q = 0; q < GR; ++q) v[q] = GT::value(g[q]);
+                for (int r = 0; r < KR; ++r) v[r] = GT::value(g, r);
             } else {
                 const float *prow = a.P + (uint64_t)u * k;
 #pragma unroll
-                for (int q = 0; q < GR; ++q) { const unsigned e = 64u * q + lane; v[q] = e < k ? prow[e] : 0.0f; }
+                for (int r = 0; r < KR; ++r) { const unsigned e = 64u * r + lane; v[r] = e < k ? prow[e] : 0.0f; }
             }
             unsigned mv = pver + 1u;                                     // lane 0: the user, lane 1: the version the row leaves with
             mv = write_lane<0>(mv, (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
@@ -868,8 +918,7 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
                         // the empty statement keeps the compiler from turning it back into one compare and branch per granule)
                         unsigned bad = (int)(seq - sdone_seen) > kTrioRing ? 1u : 0u;
                         if (!(YUE_ABL & 1)) {
-#pragma unroll
-                            for (int q = 0; q < GR; ++q) bad |= (GT::version(gi[s][q]) ^ wi) | (GT::version(gj[s][q]) ^ wj);
+                            bad |= GT::bad(gi[s], wi) | GT::bad(gj[s], wj);
                         }
                         asm volatile("" : "+v"(bad));
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {
@@ -885,7 +934,7 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
                         }
                         float v[2 * KR];
 #pragma unroll
-                        for (int q = 0; q < GR; ++q) { v[q] = GT::value(gi[s][q]); v[KR + q] = GT::value(gj[s][q]); }
+                        for (int r = 0; r < KR; ++r) { v[r] = GT::value(gi[s], r); v[KR + r] = GT::value(gj[s], r); }
                         unsigned mv = wj;                            // lanes 0..3: the two items, the two ordinals (the S waves add the rest)
                         if (!(YUE_ABL & 4)) {
                             mv = write_lane<0>(mv, (unsigned)ti);
