@@ -212,7 +212,8 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *   "replay_levels" 1 = yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path, kept for
  *               comparison; same results)
  * Read-only (yue_get_option): "chain_last_runs" / "chain_last_waves" (runs walked / waves launched by the last exact launch),
- *   "chain_last_us" (HIP-event time of that launch alone, microseconds), "round_last_user_seq" (1: the last epoch ran k_round_u),
+ *   "scan_last_few_users" (users of the last two-phase scan whose first 512 items held fewer than N candidates: they alone went
+ *   through the fused kernel over all items), "chain_last_us" (HIP-event time of that launch alone, microseconds), "round_last_user_seq" (1: the last epoch ran k_round_u),
  *   "comm_last_compute_waits" (times the compute stream waited for the collective stream in the last epoch: 1),
  *   "replay_last_levels" (dependency levels of the last levelled replay), "scan_last_chunks" (filter + select launches of the
  *   last two-phase scan; 0: the fused kernel ran), "scan_last_settle" (1: most sampled users were settled against the catalogue's

@@ -307,3 +307,37 @@ def test_two_phase_scan_with_settled_users(dev, orc, m, n, k, N):
     finally:
         dev.set_option('scan_two_phase', 1)
     assert np.array_equal(ids, ids_f) and np.array_equal(sc, sc_f)
+
+
+def test_two_phase_scan_with_a_heavy_listener_of_the_catalogues_head(dev, orc):
+    """A few users have listened to almost all of the first 512 items: their first chunk holds fewer than N candidates.  Only they
+    go through the fused kernel over all items (option-free: scan_last_few_users says how many), everybody else through the
+    filter / select pair; every list and score equals the oracle's.  A user with too few candidates in the WHOLE catalogue still
+    raises, as the reference does (base/IterativeRecommender.py:126)."""
+    m, n, k, N = 6000, 20000, 64, 20
+    P, Q, indptr, indices = _rand_problem(m, n, k, 30, seed=77, signed=True)
+    # users 5, 4000 and 5999: the first 600 items minus a handful, plus their own
+    rows = [indices[indptr[u]:indptr[u + 1]] for u in range(m)]
+    rs = np.random.RandomState(3)
+    for u, keep in ((5, 7), (4000, 19), (5999, 0)):
+        head = np.setdiff1d(np.arange(600, dtype=np.int32), rs.choice(600, size=keep, replace=False).astype(np.int32))
+        rows[u] = np.union1d(rows[u], head).astype(np.int32)
+    indptr2 = np.zeros(m + 1, np.int64)
+    indptr2[1:] = np.cumsum([len(r) for r in rows])
+    indices2 = np.concatenate(rows).astype(np.int32)
+    dev.set_factors(P, Q)
+    dev.set_interactions(indptr2, indices2, indptr2, indices2)       # (events = the listened items, once each: only the mask matters here)
+    users = np.arange(m, dtype=np.int32)
+    ids, sc = dev.topn_scan(users, N)
+    assert dev.get_option('scan_last_chunks') > 0 and dev.get_option('scan_last_few_users') == 3
+    mp, mi = mask_rows(indptr2, indices2, users)
+    oid, osc, rc = orc.topn_scan(P, Q, users, N, mp, mi)
+    assert rc == 0 and np.array_equal(ids, oid) and np.array_equal(sc, osc)
+    # one user who has listened to everything but N - 1 items
+    rows[17] = np.setdiff1d(np.arange(n, dtype=np.int32), np.arange(100, 100 + N - 1, dtype=np.int32))
+    indptr3 = np.zeros(m + 1, np.int64)
+    indptr3[1:] = np.cumsum([len(r) for r in rows])
+    indices3 = np.concatenate(rows).astype(np.int32)
+    dev.set_interactions(indptr3, indices3, indptr3, indices3)
+    with pytest.raises(IndexError):
+        dev.topn_scan(users, N)

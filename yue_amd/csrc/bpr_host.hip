@@ -796,6 +796,7 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "scan_growth") *value = c->opt_scan_growth;
     else if (key == "scan_filter_ub") *value = c->opt_scan_filter_ub;
     else if (key == "scan_last_chunks") *value = c->scan_chunks;
+    else if (key == "scan_last_few_users") *value = c->scan_few_users;
     else if (key == "scan_last_settle") *value = c->scan_settle;
     else if (key == "topn_true") *value = c->opt_topn_true;
     else if (key == "round_stage") *value = c->opt_round_stage;

@@ -64,7 +64,7 @@ int yue_ctx_destroy(yue_ctx *c) {
     c->xu.release(); c->xi.release(); c->xj.release(); c->xk.release(); c->x_loss.release(); c->scal.release();
     c->aU_m.release(); c->aU_v.release(); c->aV_m.release(); c->aV_v.release();
     c->s_users.release(); c->s_ids.release(); c->s_mask_idx.release(); c->s_flags.release();
-    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release(); c->s_work.release(); c->s_qb.release(); c->s_masks.release();
+    c->s_mask_ptr.release(); c->s_scores.release(); c->s_row.release(); c->s_norms.release(); c->s_work.release(); c->s_qb.release(); c->s_masks.release(); c->s_few.release(); c->s_few_ids.release(); c->s_few_scores.release();
     c->fP.release(); c->fBi.release(); c->f_coef.release(); c->f_x.release(); c->f_hist.release(); c->f_scores.release();
     c->f_out_sc.release(); c->fQ.release(); c->f_ptr.release(); c->f_items.release(); c->f_negs.release(); c->f_ids.release(); c->f_flags.release();
     c->f_uq_ptr.release(); c->f_neg_ptr.release(); c->f_uq_items.release(); c->f_loc_i.release(); c->f_loc_j.release();

@@ -89,6 +89,9 @@ struct yue_ctx {
     std::vector<int64_t> h_ev_ptr;       // host copy: user -> first event
     // scoring scratch
     DevBuf<int32_t> s_users, s_ids, s_mask_idx, s_flags;
+    DevBuf<int32_t> s_few, s_few_ids;   // two-phase scoring: positions / ids of the users with fewer than N candidates in the first chunk, their lists
+    DevBuf<float> s_few_scores;
+    int64_t scan_few_users = 0;         // such users of the last scan (read-only option scan_last_few_users)
     DevBuf<int64_t> s_mask_ptr;
     DevBuf<float> s_scores, s_row, s_norms;
     double scan_ms = 0.0;

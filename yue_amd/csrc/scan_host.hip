@@ -65,6 +65,7 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
     HIPCHK(hipEventRecord(t0, c->stream));
     int rc = 0;
     c->scan_chunks = 0;
+    c->scan_few_users = 0;
     // Long catalogues: the first chunk through the fused kernel (it seeds the lists), the rest in chunks of doubling size
     // through k_scan_filter / k_scan_select (score2_kernels.hpp).  Same lists and scores by construction.
     constexpr int64_t kChunk0 = 512;       // (the fused kernel is slow where the thresholds still move fast)
@@ -97,7 +98,26 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
         const bool settle = 2u * settle_host[1] > settle_host[0];
         c->scan_settle = settle ? 1 : 0;
         const int growth = c->opt_scan_growth > 0 ? c->opt_scan_growth : ((double)ev0 / (double)nu > 4.0 * N ? 2 : 8);
-        if (few) {      // some user has fewer than N candidates among the first items: let the fused kernel walk everything
+        // Some users have fewer than N unmasked candidates among the first items (a heavy listener of the catalogue's head): with the
+        // training CSR as the mask they alone go through the fused kernel over all items afterwards, everybody else through the
+        // filter / select pair as usual.  (An explicit mask is indexed by position in users[]: there the whole call falls back.)
+        int64_t nfew = 0;
+        if (few && sa.mask_by_user) {
+            HIPCHK(c->s_few.resize((size_t)(2 * nu + 2)));
+            unsigned *cnt = reinterpret_cast<unsigned *>(c->s_few.p + 2 * nu);
+            HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned), c->stream));
+            hipLaunchKernelGGL(yue::k_scan_collect_few, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, c->stream, c->s_ids.p, c->s_scores.p, c->s_users.p, nu, N,
+                               c->s_few.p, c->s_few.p + nu, cnt);
+            unsigned h = 0;
+            HIPCHK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemsetAsync(c->s_flags.p, 0, sizeof(int32_t), c->stream));          // (the fused pass over these users raises it again if they really have too few)
+            HIPCHK(hipStreamSynchronize(c->stream));
+            nfew = h;
+        }
+        c->scan_few_users = nfew;
+        if (few && (!sa.mask_by_user || nfew > std::max<int64_t>(64, nu / 8))) {      // explicit masks, or too many such users: the fused kernel walks everything
+            nfew = 0;
+            c->scan_few_users = 0;
             HIPCHK(hipMemsetAsync(c->s_flags.p, 0, 4 * sizeof(int32_t), c->stream));
             HIPCHK(hipMemsetAsync(c->s_work.p, 0, 4 * yue::kWorkSlots * sizeof(unsigned long long), c->stream));
         } else {
@@ -150,6 +170,14 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
                     hipLaunchKernelGGL((yue::k_scan_select<kSelWaves>), dim3((unsigned)((un + kSelWaves - 1) / kSelWaves)), dim3(64 * kSelWaves), sel_lds, c->stream, xa);
                     if (u0 == 0) c->scan_chunks++;
                 }
+            }
+            if (nfew > 0) {      // the few-candidates users: the fused kernel over all items, rows back to their places
+                HIPCHK(c->s_few_ids.resize((size_t)(nfew * N))); HIPCHK(c->s_few_scores.resize((size_t)(nfew * N)));
+                yue::ScanArgs sf = sa;
+                sf.users = c->s_few.p + nu; sf.nu = nfew; sf.out_ids = c->s_few_ids.p; sf.out_scores = c->s_few_scores.p;
+                (void)yue::launch_scan(sf, c->stream, 0, 0);
+                hipLaunchKernelGGL(yue::k_scan_scatter_rows, dim3((unsigned)((nfew * N + 255) / 256)), dim3(256), 0, c->stream, c->s_few_ids.p, c->s_few_scores.p,
+                                   c->s_few.p, nfew, N, c->s_ids.p, c->s_scores.p);
             }
             HIPCHK(hipGetLastError());
             done = true;

@@ -67,6 +67,26 @@ __global__ void __launch_bounds__(256) k_scan_settled_sample(const float *P, con
     if (lane == 0 && sampled) { atomicAdd(counts, sampled); atomicAdd(counts + 1, settled); }
 }
 
+// Users whose first chunk held fewer than N unmasked candidates (the fused kernel left id -1 in their rows): their positions and
+// ids into a list for a fused scan over ALL items of just these users (yue_topn_scan), and a threshold of +infinity into their
+// rows so that the filter / select pair finds nothing to do for them meanwhile.
+__global__ void __launch_bounds__(256) k_scan_collect_few(const int32_t *ids, float *scores, const int32_t *users, int64_t nu, int N,
+                                                          int32_t *few_pos, int32_t *few_users, unsigned *count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nu || ids[t * N] >= 0) return;
+    const unsigned q = atomicAdd(count, 1u);
+    few_pos[q] = (int32_t)t; few_users[q] = users[t];
+    scores[t * N + N - 1] = INFINITY;
+}
+// rows of the few-candidates users' lists back to their places
+__global__ void __launch_bounds__(256) k_scan_scatter_rows(const int32_t *src_ids, const float *src_scores, const int32_t *pos, int64_t count, int N,
+                                                           int32_t *ids, float *scores) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * N) return;
+    const int64_t row = t / N, col = t - row * N;
+    ids[(int64_t)pos[row] * N + col] = src_ids[t]; scores[(int64_t)pos[row] * N + col] = src_scores[t];
+}
+
 // A wave takes UB blocks of 32 users: one item-tile fragment read from LDS feeds UB MFMAs (at UB = 1 the LDS reads of the
 // fragments take as long as the MFMAs they feed: 16 x 1 KB per wave and 64 items against 16 x 32 cycles of the matrix pipe).
 template <int K16, int WAVES, int UB, bool SETTLE>
