@@ -129,6 +129,52 @@ def test_rounds_of_one_equal_sequential(orc):
     assert abs(a - b) < 1e-9 * abs(a)
 
 
+def test_rounds_with_sequential_user_rows_are_pinned_to_the_sequential_loop(orc):
+    """orc_bpr_rounds_seq_user (round 4: user rows sequential, item rows under round semantics): a round of ONE triplet is the
+    reference's loop on the reference's own triplet stream (up to the x + (x' - x) rounding of the two item rows); with whole users
+    per round the user rows only differ from the sequential loop's through the staleness of the item rows -- and a round that holds
+    every item at most once IS the sequential loop."""
+    z, _, _, E = _case('d2_k64_e1')
+    m, n, k = int(z['m']), int(z['n']), int(z['k'])
+    P1, Q1 = synth.init_factors(m, n, k, 7)
+    P2, Q2 = P1.copy(), Q1.copy()
+    T = 2000
+    a = orc.bpr_sequential(P1, Q1, z['u'][:T], z['i'][:T], z['j'][:T], 0.02, 0.01, 0.01)
+    b = orc.bpr_rounds_seq_user(P2, Q2, z['u'][:T], z['i'][:T], z['j'][:T], np.arange(T + 1), 0.02, 0.01, 0.01)
+    assert rel_err(P2, P1) < 2e-6 and rel_err(Q2, Q1) < 2e-6 and abs(a - b) < 1e-9 * abs(a)
+    # one user, every item touched once, all in ONE round: no item row is read after it was written -> the sequential loop again
+    rs = np.random.RandomState(1)
+    items = rs.permutation(n)[:200].astype(np.int32)
+    u = np.zeros(100, np.int32)
+    P3, Q3 = synth.init_factors(m, n, k, 9)
+    P4, Q4 = P3.copy(), Q3.copy()
+    a = orc.bpr_sequential(P3, Q3, u, items[:100], items[100:], 0.02, 0.01, 0.01)
+    b = orc.bpr_rounds_seq_user(P4, Q4, u, items[:100], items[100:], np.array([0, 100], np.int64), 0.02, 0.01, 0.01)
+    assert np.array_equal(P4, P3) and rel_err(Q4, Q3) < 2e-6 and abs(a - b) < 1e-12 * abs(a)
+    # and the plain S-round (user row summed over the round) is NOT: the difference the round-4 form removes
+    P5, Q5 = synth.init_factors(m, n, k, 9)
+    orc.bpr_rounds(P5, Q5, u, items[:100], items[100:], np.array([0, 100], np.int64), 0.02, 0.01, 0.01)
+    assert rel_err(P5, P3) > 1e-4
+
+
+def test_dataflow_timing_model(orc):
+    """orc_dataflow_model (a timing model of the exact path's launch, not a checker): hand-checkable cases."""
+    u = np.array([0, 0, 0, 1, 1, 2], np.int32)
+    i = np.array([0, 1, 2, 3, 4, 0], np.int32)
+    j = np.array([5, 6, 7, 8, 9, 6], np.int32)
+    # no shared rows except run 2 (user 2) touching items 0 and 6 of run 0: independent runs in parallel
+    t, hops = orc.dataflow_model(u, i, j, 10, 8, 1.0, 0.5, 2.0, 2.0)
+    # run 0: 1 + 3 * 0.5 = 2.5; run 2 starts at 1.0 but needs item 0 (ready 1.5 + 2) and item 6 (ready 2.0 + 2): 4.0 + 0.5
+    assert abs(t - 4.5) < 1e-12 and hops == 1
+    # one worker: the runs queue up (run 1 starts when run 0 is done)
+    t1, _ = orc.dataflow_model(u, i, j, 10, 1, 1.0, 0.5, 2.0, 2.0)
+    assert abs(t1 - (2.5 + 1.0 + 1.0 + 1.0 + 0.5)) < 1e-12
+    # a skipped triplet costs nothing
+    j2 = j.copy(); j2[1] = -1
+    t2, _ = orc.dataflow_model(u, i, j2, 10, 8, 1.0, 0.5, 0.0, 0.0)
+    assert abs(t2 - 2.0) < 1e-12
+
+
 def test_counter_sampler_properties(orc):
     ev = gz('g2_events_c1.npz')
     m, n = 1000, 1000
