@@ -60,7 +60,48 @@ def scan(listing, need=5):
     return bad
 
 
+VREG = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+
+
+def _vregs(text):
+    out = set()
+    for m in VREG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def scan_wide_stores(listing, need=2):
+    """A vector-memory store of more than 64 bits reads its data registers late: a VALU instruction that writes one of them needs
+    `need` wait states behind the store (the compiler counts them for its own stores; the hand-written granule-pair stores carry
+    an s_nop inside their statement).  -> list of (line number, store, overwriting instruction)."""
+    bad = []
+    pending = []                                        # [data registers, wait states since the store, line, text]
+    for ln, raw in enumerate(listing.splitlines(), 1):
+        line = raw.split(';')[0].strip()
+        if not line or line.endswith(':') or line.startswith('.'):
+            continue
+        parts = line.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else '')
+        if op.startswith('v_') and pending:
+            dst = _vregs(args.split(',')[0])
+            for regs, age, sl, st in pending:
+                if age < need and dst & regs:
+                    bad.append((sl, st, line))
+        step = int(args.strip(), 0) + 1 if op == 's_nop' else 1
+        pending = [[r, a + step, sl, st] for r, a, sl, st in pending if a + step < need]
+        if re.match(r'(buffer|global|flat)_store_dwordx[34]', op):
+            pending.append([_vregs(args.split(',')[0]), 0, ln, line])
+    return bad
+
+
 def test_checker_sees_the_hazard_and_the_guard():
+    wide = "\tbuffer_store_dwordx4 v[4:7], v9, s[4:7], s9 offen sc1\n\tv_mov_b32_e32 v5, v1\n"
+    assert len(scan_wide_stores(wide)) == 1
+    assert scan_wide_stores(wide.replace('\tv_mov', '\ts_nop 1\n\tv_mov')) == []
+    assert scan_wide_stores(wide.replace('v5, v1', 'v8, v1')) == [] and scan_wide_stores(wide.replace('dwordx4 v[4:7]', 'dwordx2 v[4:5]')) == []
     racy = "\tv_readfirstlane_b32 s4, v1\n\tv_readfirstlane_b32 s5, v2\n\tbuffer_load_dwordx2 v[0:1], v3, s[4:7], 0 offen sc1\n"
     assert [b[2] for b in scan(racy)] == [4, 5]
     assert scan(racy.replace('\tbuffer', '\ts_nop 4\n\tbuffer')) == []
@@ -81,3 +122,5 @@ def test_exact_path_listing_has_no_valu_sgpr_to_vmem_hazard(tmp_path):
     assert text.count('buffer_load_dwordx2') + text.count('buffer_load_dwordx4') > 100 and text.count('s_nop 4') > 50       # the listing is the one with the hand-written accesses
     bad = scan(text)
     assert not bad, bad[:10]
+    wide = scan_wide_stores(text)
+    assert text.count('buffer_store_dwordx4') > 50 and not wide, wide[:10]

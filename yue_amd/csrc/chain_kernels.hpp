@@ -185,12 +185,14 @@ struct GranRow {
     }
     static __device__ __forceinline__ void store(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) {
         if constexpr (KR == 1) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
-        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
+        // (a vector-memory store of more than 64 bits reads its data registers late: a VALU write of them needs 2 wait states
+        // behind it -- the compiler counts those for its own stores, not for this one, hence the s_nop inside the statement)
+        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
     }
     // the same store left in the XCD's L2 (no write-through): only for a launch whose waves ALL sit behind one L2 (k_bpr_chain3<.., ONE_XCD>)
     static __device__ __forceinline__ void store_l2(const reg &d, unsigned vo, const i32x4 &rs, unsigned so) {
         if constexpr (KR == 1) asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
-        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
+        else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(vo), "s"(rs), "s"(so) : "memory");
     }
     // element r (0 .. KR - 1) of the row
     static __device__ __forceinline__ float value(const reg (&g)[NL], int r) {
