@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256) k_round_u(TrainArgs a, RoundUArgs ra, con
         };
         // a ring of D events: the rows of event t + D are requested when event t has been taken (lanes past the segment's end
         // hold item 0 / no negative: their gathers read row 0 and are never looked at)
-        constexpr int D = 4;
+        constexpr int D = KR == 1 ? 8 : 4;               // events in flight per wave (k <= 64, rows of 256 bytes: 8 -- config 2 2.31e9 -> 2.43e9 triplets/s; 16 there, or 8 at k = 128, change nothing)
         float qi[D][KR], qj[D][KR];
 #pragma unroll
         for (int s_ = 0; s_ < D; ++s_) gather(qi[s_], qj[s_], (unsigned)s_);
