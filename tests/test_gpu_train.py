@@ -632,3 +632,25 @@ def test_epoch_with_the_single_precision_coefficient_stays_within_tolerance(orc)
         dev.close()
         print('k=%d: rel P %.2e Q %.2e, bit-equal P %.3f Q %.3f' % (k, rel_err(P, Po), rel_err(Q, Qo), np.mean(P == Po), np.mean(Q == Qo)))
         assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL
+
+
+@pytest.mark.parametrize('k', [64, 128, 200])
+def test_epoch_with_users_of_more_than_one_header_segment(orc, k):
+    """150 events per user: k_round_u walks a user in segments of 64 events (headers in register lanes, the gather ring wraps
+    inside a segment); k_round_m takes them 8 at a time anyway.  Against the restatement of the module's current semantics."""
+    from yue_amd._shim import Device
+    m, n, d, W = 300, 2000, 150, 4000
+    data, P0, Q0, ev_u = _synth_problem(m, n, d, k, seed=31)
+    rp = np.array(epoch_round_ptr(data['ev_ptr'], W), np.int64)
+    dev = Device(0, raise_errors=True)
+    dev.set_factors(P0, Q0)
+    dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
+    Po, Qo = P0.copy(), Q0.copy()
+    for epoch in range(2):
+        j = dev.sample_negatives(8, epoch)
+        nll, _, _ = dev.bpr_epoch(8, epoch, W, 0.02, 0.01, 0.01)
+        nll_o = _epoch_oracle(orc)(Po, Qo, ev_u, data['ev_i'], j, rp, 0.02, 0.01, 0.01)
+        assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    P, Q = dev.get_factors()
+    dev.close()
+    assert rel_err(P, Po) < TOL and rel_err(Q, Qo) < TOL

@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(320) k_bpr_chain3(ChainArgs a, const int32_t *
     constexpr uint32_t kIdleLimit = 1u << 30;
     uint32_t idle = 0;
     auto nap = [&]() -> bool {                           // false: give up (status set by somebody, or the idle bound)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(1);                     // (spinning without the sleep changes neither the step nor the hop)
         if (__builtin_expect((++idle & 0xfffu) == 0u, 0)) {
             if (idle >= kIdleLimit) { if (lane == 0) atomicOr(a.status, 4u); return false; }
             if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
