@@ -150,8 +150,8 @@ def _exact_epoch(dev, data, P0, Q0, seed, split, fast, epochs=1, xcd=0):
 
 
 @pytest.mark.parametrize('m,n,d,k', [(3000, 2000, 20, 128), (5000, 64, 12, 64), (700, 900, 70, 10), (400, 300, 25, 200)])
-def test_three_wave_variant_is_bit_equal(dev, m, n, d, k):
-    """Option chain_split: a run walked by three waves (loads / dependency chain / stores, hand-over through LDS) must produce
+def test_wave_group_variant_is_bit_equal(dev, m, n, d, k):
+    """Option chain_split: a run walked by a group of five waves (2 x loads / dependency chain / 2 x stores, hand-over through LDS) must produce
     exactly the factors (and the loss) of the one-wave kernel (70 events per user: runs longer than one segment of 64;
     5000 users on 64 items: the ring of packets is full of rows that wait for the same group's own stores) -- on all XCDs with
     write-through hand-offs, and with every working wave on ONE XCD and the rows handed over through its L2 (option chain_xcd)."""
@@ -164,9 +164,9 @@ def test_three_wave_variant_is_bit_equal(dev, m, n, d, k):
     print('one XCD: %d waves stayed' % dev.get_option('chain_last_waves'))
 
 
-def test_three_wave_replay_of_an_interleaved_stream_is_bit_equal(dev):
+def test_wave_group_replay_of_an_interleaved_stream_is_bit_equal(dev):
     """The general stream (users come back: user rows versioned per run, skipped triplets, items repeated inside a run) through
-    the three-wave kernel lands on the one-wave kernel's factors."""
+    the wave-group kernel lands on the one-wave kernel's factors."""
     rs = np.random.RandomState(79)
     m, n, k, T = 300, 500, 128, 40000
     P0, Q0 = synth.init_factors(m, n, k, 80)

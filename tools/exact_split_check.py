@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One exact epoch with the one-wave and the two-wave kernel on the same problem: results must be bit-equal."""
+"""One exact epoch with the one-wave kernel (chain_split = 0) and the wave-group kernel (chain_split = 1) on the same problem: results must be bit-equal."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -151,8 +151,8 @@ struct yue_ctx {
     int opt_epoch_exact = 0;             // 1: yue_bpr_epoch applies the epoch's triplets with exact sequential semantics (k_bpr_chain)
     int opt_replay_levels = 0;           // 1: yue_bpr_replay by host-computed dependency levels, one launch per level (the round-1 path)
     int opt_chain_split = -1;            // 1: a run is walked by a group of five waves (k_bpr_chain3: 2 x loads / dependency chain / 2 x stores); 0: by one wave (k_bpr_chain); -1: by the stream's mean run length
-    int opt_chain_ring = 0;              // three-wave kernel: triplets whose rows the loading wave keeps in flight (0 = 8; 16 for k <= 128)
-    int opt_chain_xcd = 0;               // three-wave kernel: 1 = all working waves on ONE XCD, rows handed over through its L2
+    int opt_chain_ring = 0;              // wave-group kernel: triplets whose rows a loading wave keeps in flight (0 = 8; 16 for k <= 128)
+    int opt_chain_xcd = 0;               // wave-group kernel: 1 = all working waves on ONE XCD, rows handed over through its L2
     int opt_chain_fast = 0;              // 1: single-precision coefficient, one 64-lane sum per triplet (within 1e-5, not bit-equal)
     int opt_chain_waves = 0;             // workgroups per CU of the persistent launch (0: what fits, at most 8)
     int64_t opt_chain_spin = 0;          // polls per wait before a wave gives up (0: 2^22)
