@@ -16,6 +16,9 @@ config key ``bpr.hip`` selects how an epoch runs (existing .conf files parse unc
   bpr.hip=-mode exact -seed 1           the device's counter-based sampler with the reference's EXACT sequential semantics (one dataflow
                                         launch per epoch, chain_kernels.hpp): the loop of BPR.py:42-58 on other negatives than
                                         Python's; needs no host sampling, so it also serves array-native data.
+                                        -fast 1: the step's coefficient lr (1 - sigmoid(x)) in single precision (option chain_fast):
+                                        the reference's ORDER of updates, factors within 1e-5 of its result instead of bit-equal,
+                                        1.5 x the rate.
   bpr.hip=-mode adam                    the reference's LIVE path (BPR.py:65-129, a TensorFlow-1 graph): every "iteration" is one
                                         minibatch of 512 random training events x 100 rejection-sampled negatives (next_batch,
                                         :65-81, same NumPy / random calls), loss = sum softplus(-x) + regU * l2 terms, Adam(lRate)
@@ -61,7 +64,7 @@ class BPR(IterativeRecommender):
             self.Q = _truncated_normal((self.n, self.k), 0.005)
 
     def _options(self):
-        opts = {'-mode': 'replay', '-round': 'auto', '-seed': '1'}
+        opts = {'-mode': 'replay', '-round': 'auto', '-seed': '1', '-fast': '0'}
         if self.config.contains('bpr.hip'):
             given = LineConfig(self.config['bpr.hip'])
             for key in opts:
@@ -135,6 +138,7 @@ class BPR(IterativeRecommender):
         self._sync_factors_to_device()
         dev, arr = self.dev, self._arrays
         dev.set_option('epoch_exact', 1 if opts['-mode'] == 'exact' else 0)
+        dev.set_option('chain_fast', 1 if opts['-fast'] not in ('0', '', 'off', 'false') else 0)
         if opts['-mode'] == 'replay':
             ev_u = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(arr['ev_ptr']))
             listened_names = {user: {ev[self.recType] for ev in events} for user, events in self.data.userRecord.items()}
