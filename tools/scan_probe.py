@@ -23,9 +23,9 @@ for ep in range(epochs):
     dev.bpr_epoch(20260003, ep, 0, 0.02, 0.01, 0.01)
 users = np.arange(nu, dtype=np.int32)
 ref = None
-configs = [('default (two-phase, growth chosen from the first chunk)', {})] if os.environ.get('PROBE_DEFAULT') else None
+configs = [('default (two-phase, growth chosen from the first chunk)', {'scan_filter_ub': int(os.environ['PROBE_FORM'])} if os.environ.get('PROBE_FORM') else {})] if os.environ.get('PROBE_DEFAULT') else None
 if os.environ.get('PROBE_UB'):          # one or two blocks of users per filter wave
-    configs = [('two-phase, 1 user block per wave', {'scan_filter_ub': 1}), ('two-phase, 2 user blocks per wave', {'scan_filter_ub': 2}), ('two-phase, 1 user block per wave', {'scan_filter_ub': 1})]
+    configs = [('two-phase, filter form %d' % v, {'scan_filter_ub': v}) for v in (1, 2, 1, 2)]
 for label, opts in configs or [('fused', {'scan_two_phase': 0}), ('two-phase x2', {'scan_two_phase': 1, 'scan_growth': 2}), ('two-phase x4', {'scan_two_phase': 1, 'scan_growth': 4}),
                     ('two-phase x8', {'scan_two_phase': 1, 'scan_growth': 8}), ('two-phase x16', {'scan_two_phase': 1, 'scan_growth': 16})]:
     for a, b in opts.items():

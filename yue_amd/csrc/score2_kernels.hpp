@@ -87,10 +87,12 @@ __global__ void __launch_bounds__(256) k_scan_scatter_rows(const int32_t *src_id
     ids[(int64_t)pos[row] * N + col] = src_ids[t]; scores[(int64_t)pos[row] * N + col] = src_scores[t];
 }
 
-// A wave takes UB blocks of 32 users: one item-tile fragment read from LDS feeds UB MFMAs (at UB = 1 the LDS reads of the
-// fragments take as long as the MFMAs they feed: 16 x 1 KB per wave and 64 items against 16 x 32 cycles of the matrix pipe).
+// A wave takes UB blocks of 32 users: one item-tile fragment read from LDS feeds UB MFMAs.  The library's form is UB = 2 in
+// workgroups of four waves (the same 256 users per workgroup as UB = 1 with eight): 168 VGPRs = three waves per SIMD, one from
+// each of three workgroups, half the LDS reads and half the barriers per MFMA (config 5, factors of 25 epochs: 55 against 69 ms
+// per scan on the same box, the matrix pipe busy 64 % of the filter's cycles against 54 %; the shader clock falls to 1.7 GHz).
 template <int K16, int WAVES, int UB, bool SETTLE>
-__global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(UB == 2 ? 3 : 2))) k_scan_filter(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int K = 16 * K16, LDB = K + kScanBfPad, NT = 64 * WAVES, ROWS = 64;
     __bf16 *btile = reinterpret_cast<__bf16 *>(lds_raw);                 // [2][64][LDB]
@@ -148,6 +150,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
     for (int b = 0; b < UB; ++b) summ[b] = 0u;
     if (it_begin >= niter) return;
     float sm_next = SETTLE ? a.tile_norm_sufmax[(a.item0 + it_begin * ROWS) / kScanTile] : 0.0f;
+    float nu0_next, nu1_next;
+    {
+        const int64_t i0 = a.item0 + it_begin * ROWS;
+        nu0_next = a.tile_norm_max[i0 / kScanTile]; nu1_next = (i0 + kScanTile < a.n) ? a.tile_norm_max[i0 / kScanTile + 1] : 0.0f;
+    }
     fetch(a.item0 + it_begin * ROWS);
     commit((int)(it_begin & 1));
     __syncthreads();
@@ -181,63 +188,68 @@ __global__ void __launch_bounds__(64 * WAVES) k_scan_filter(FilterArgs a) {
             }
         }
         const __bf16 *tbb = btile + stage * ROWS * LDB;
-        if (it + 1 < niter) fetch(it0 + ROWS);
-        const int64_t tl = it0 / kScanTile;
-        const float nu0 = a.tile_norm_max[tl], nu1 = (it0 + kScanTile < a.n) ? a.tile_norm_max[tl + 1] : 0.0f;
+        // the norms of the NEXT stage's tiles are asked for here, in front of the next stage's rows: their latency (and the
+        // vmcnt(0) the compiler puts in front of their first use) would otherwise open every stage
+        const float nu0 = nu0_next, nu1 = nu1_next;
+        if (it + 1 < niter) {
+            const int64_t tn = (it0 + ROWS) / kScanTile;
+            nu0_next = a.tile_norm_max[tn]; nu1_next = (it0 + ROWS + kScanTile < a.n) ? a.tile_norm_max[tn + 1] : 0.0f;
+            fetch(it0 + ROWS);
+        }
         bool settled = true;                                 // Cauchy-Schwarz: no exact score of these tiles reaches the threshold
 #pragma unroll
         for (int b = 0; b < UB; ++b) settled = settled && (!uvalid[b] || pn[b] * fmaxf(nu0, nu1) <= thr[b]);
         if (__ballot(!settled) != 0ull) {
             tiles_done += 2 * UB;
             uint32_t pm[UB][2];
+            auto sift = [&](const f32x16 &sc, int b, int q) {
+                const float bar = thr[b] - mu[b] * (q ? nu1 : nu0);
+                // most tiles hold no survivor for any user of the wave: one max over the lane's 16 scores decides that
+                float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                f32x16 acc[UB];
+                for (int z = 3; z < 15; z += 2) mx = fmaxf(fmaxf(mx, sc[z]), sc[z + 1]);
+                mx = fmaxf(mx, sc[15]);
+                pm[b][q] = 0u;
+                if (__ballot(bar < mx) != 0ull) {
+                    uint32_t bits = 0u;
+#pragma unroll
+                    for (int z = 15; z >= 0; --z) bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(uint32_t, bar - sc[z]), 31);
+                    const uint32_t pmask = (bits & 0xFu) | ((bits & 0xF0u) << 4) | ((bits & 0xF00u) << 8) | ((bits & 0xF000u) << 12);
+                    pm[b][q] = pmask << (4 * h);
+                }
+            };
+            // The stage's 2 K16 item fragments as ONE stream through a ring of RD registers, each ds_read_b128 RD - 1 k-steps
+            // ahead of its UB MFMAs and across the seam between the two tiles (the scheduling barriers pin that order: left to
+            // itself the compiler issues two reads and waits for them in front of two MFMAs).  UB = 1: the second tile
+            // accumulates beside the first, whose survivors are sifted under the second's MFMAs; UB = 2: one generation of
+            // accumulators (af[2][K16] + two generations would not leave three waves per SIMD).
+            constexpr int J = 2 * K16, RD = J < 4 ? J : 4, SIFT0 = UB == 1 ? (K16 + 2 < J ? K16 + 2 : J - 1) : K16 - 1;
+            const __bf16 *irow = tbb + r * LDB + 8 * h;
+            auto frag = [&](int j) { return *reinterpret_cast<const bf16x8 *>(irow + (j / K16) * kScanTile * LDB + 16 * (j % K16)); };
+            bf16x8 ring[RD];
+#pragma unroll
+            for (int j = 0; j < RD - 1; ++j) ring[j] = frag(j);
+            f32x16 acc[2][UB];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int b = 0; b < UB; ++b)
 #pragma unroll
-                    for (int z = 0; z < 16; ++z) acc[b][z] = 0.0f;
-                const __bf16 *irow = tbb + (q * kScanTile + r) * LDB + 8 * h;
-                if (UB == 1) {
+                    for (int z = 0; z < 16; ++z) acc[q][b][z] = 0.0f;
 #pragma unroll
-                    for (int s = 0; s < K16; ++s) {
-                        const bf16x8 itf = *reinterpret_cast<const bf16x8 *>(irow + 16 * s);
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(itf, af[0][s], acc[0], 0, 0, 0);
-                    }
-                } else {
-                    // the item fragments through a ring of three registers (ds_read_b128 two k-steps ahead of its UB MFMAs): left to
-                    // itself the compiler keeps all K16 fragments live beside af[UB][K16] and acc[UB] -- 162 VGPRs, one workgroup
-                    // fewer per CU (round 3).  The empty statements pin the order: a read may not move above the one in front of it.
-                    bf16x8 ring[3];
-                    ring[0] = *reinterpret_cast<const bf16x8 *>(irow);
-                    if (K16 > 1) ring[1] = *reinterpret_cast<const bf16x8 *>(irow + 16);
+            for (int j = 0; j < J; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + RD - 1 < J) ring[(j + RD - 1) % RD] = frag(j + RD - 1);
 #pragma unroll
-                    for (int s = 0; s < K16; ++s) {
-                        asm volatile("" ::: "memory");
-                        if (s + 2 < K16) ring[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(irow + 16 * (s + 2));
-                        asm volatile("" ::: "memory");
+                for (int b = 0; b < UB; ++b) acc[j / K16][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j % RD], af[b][j % K16], acc[j / K16][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == SIFT0) {
 #pragma unroll
-                        for (int b = 0; b < UB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[s % 3], af[b][s], acc[b], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < UB; ++b) {
-                    const float bar = thr[b] - mu[b] * (q ? nu1 : nu0);
-                    // most tiles hold no survivor for any user of the wave: one max over the lane's 16 scores decides that
-                    float mx = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]);
-#pragma unroll
-                    for (int z = 3; z < 15; z += 2) mx = fmaxf(fmaxf(mx, acc[b][z]), acc[b][z + 1]);
-                    mx = fmaxf(mx, acc[b][15]);
-                    pm[b][q] = 0u;
-                    if (__ballot(bar < mx) != 0ull) {
-                        uint32_t bits = 0u;
-#pragma unroll
-                        for (int z = 15; z >= 0; --z) bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(uint32_t, bar - acc[b][z]), 31);
-                        const uint32_t pmask = (bits & 0xFu) | ((bits & 0xF0u) << 4) | ((bits & 0xF00u) << 8) | ((bits & 0xF000u) << 12);
-                        pm[b][q] = pmask << (4 * h);
-                    }
+                    for (int b = 0; b < UB; ++b) sift(acc[0][b], b, 0);
                 }
             }
+#pragma unroll
+            for (int b = 0; b < UB; ++b) sift(acc[1][b], b, 1);
             const int64_t left = a.n - it0;                      // items of the catalogue from this stage on
 #pragma unroll
             for (int b = 0; b < UB; ++b) {
