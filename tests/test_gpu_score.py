@@ -248,12 +248,13 @@ def test_config5_at_its_stated_size(orc):
 
 @pytest.mark.parametrize('m,n,k,N,per_user,signed', [(300, 40000, 128, 20, 60, True), (70, 33000, 64, 5, 2000, False), (130, 20000, 16, 64, 30, True),
                                                    (40, 50001, 32, 10, 0, False), (257, 17000, 128, 1, 100, True)])
-@pytest.mark.parametrize('form', [2, 1])
+@pytest.mark.parametrize('form', [3, 2, 1])
 def test_two_phase_scan_equals_the_fused_kernel_and_the_oracle(dev, orc, m, n, k, N, per_user, signed, form):
     """Catalogues of 16,384 items and more take the chunked path (k_topn_scan_bf16p for the first 512 items, then
     k_scan_filter + k_scan_select per chunk of doubling size): lists and scores must equal the oracle's and the fused
     kernel's, with the overwrite-scan and as a true top-N, with ties, heavy masks (more than fit in LDS) and odd sizes; in
-    both forms of the filter (scan_filter_ub = 2: two blocks of 32 users per wave, the default; 1: one block, eight waves)."""
+    all forms of the filter (scan_filter_ub = 3: two blocks of 32 users per wave and item rows by DMA, the default; 2: rows
+    through registers; 1: one block, eight waves)."""
     P, Q, indptr, indices = _rand_problem(m, n, k, per_user, seed=1000 + k + N, signed=signed)
     Q[5000:5003] = Q[123]                                      # equal rows: ties between far-apart items
     users = np.arange(m, dtype=np.int32)[::-1].copy()
@@ -273,13 +274,13 @@ def test_two_phase_scan_equals_the_fused_kernel_and_the_oracle(dev, orc, m, n, k
         finally:
             dev.set_option('scan_two_phase', 1)
             dev.set_option('topn_true', 0)
-            dev.set_option('scan_filter_ub', 2)
+            dev.set_option('scan_filter_ub', 3)
         assert np.array_equal(ids, ids_f) and np.array_equal(sc, sc_f) and events == events_f
         oid, osc, rc = (orc.topn_true if true_topn else orc.topn_scan)(P, Q, users, N, mp, mi)
         assert np.array_equal(ids, oid) and np.array_equal(sc, osc)
 
 
-@pytest.mark.parametrize('form', [2, 1])
+@pytest.mark.parametrize('form', [3, 2, 1])
 @pytest.mark.parametrize('m,n,k,N', [(1500, 60000, 128, 20), (700, 40000, 64, 10)])
 def test_two_phase_scan_with_settled_users(dev, orc, m, n, k, N, form):
     """Item norms that fall along the catalogue (what a few epochs of training leave on popularity-ordered items): most users
@@ -303,7 +304,7 @@ def test_two_phase_scan_with_settled_users(dev, orc, m, n, k, N, form):
     try:
         ids, sc = dev.topn_scan(users, N, mp, mi)
     finally:
-        dev.set_option('scan_filter_ub', 2)
+        dev.set_option('scan_filter_ub', 3)
     assert dev.get_option('scan_last_chunks') >= 2 and dev.get_option('scan_last_settle') == 1
     done, total = dev.scan_work()
     assert done < 0.5 * total                                   # most tiles were never scored

@@ -16,6 +16,12 @@ m, n, d, k, N = 1000000, 200000, 50, 128, 20
 nu = int(sys.argv[2]) if len(sys.argv) > 2 else m
 data = synth.make_arrays(m, n, d, seed=20260001)
 P0, Q0 = synth.init_factors(m, n, k, 20260002)
+if os.environ.get('PROBE_CONSTQ') == 'row':     # timing experiments (diagnostic libraries without sifting): every item row the same / zero
+    Q0[:] = Q0[0]
+elif os.environ.get('PROBE_CONSTQ') == 'zero':
+    Q0[:] = 0
+elif os.environ.get('PROBE_CONSTQ') == 'const':
+    Q0[:] = 0.01
 dev = Device(0, raise_errors=True)
 dev.set_factors(P0, Q0)
 dev.set_interactions(data['indptr'], data['indices'], data['ev_ptr'], data['ev_i'])
@@ -25,7 +31,7 @@ users = np.arange(nu, dtype=np.int32)
 ref = None
 configs = [('default (two-phase, growth chosen from the first chunk)', {'scan_filter_ub': int(os.environ['PROBE_FORM'])} if os.environ.get('PROBE_FORM') else {})] if os.environ.get('PROBE_DEFAULT') else None
 if os.environ.get('PROBE_UB'):          # one or two blocks of users per filter wave
-    configs = [('two-phase, filter form %d' % v, {'scan_filter_ub': v}) for v in (1, 2, 1, 2)]
+    configs = [('two-phase, filter form %d' % v, {'scan_filter_ub': v}) for v in (2, 3, 2, 3)]
 for label, opts in configs or [('fused', {'scan_two_phase': 0}), ('two-phase x2', {'scan_two_phase': 1, 'scan_growth': 2}), ('two-phase x4', {'scan_two_phase': 1, 'scan_growth': 4}),
                     ('two-phase x8', {'scan_two_phase': 1, 'scan_growth': 8}), ('two-phase x16', {'scan_two_phase': 1, 'scan_growth': 16})]:
     for a, b in opts.items():

@@ -837,7 +837,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "scan_two_phase") { c->opt_scan_two_phase = value != 0; return YUE_OK; }
     if (key == "fism_lds") { c->opt_fism_lds = value != 0; return YUE_OK; }
-    if (key == "scan_filter_ub") { if (value != 1 && value != 2) return fail(YUE_ERR_ARG, "yue_set_option: scan_filter_ub must be 1 or 2"); c->opt_scan_filter_ub = (int)value; return YUE_OK; }
+    if (key == "scan_filter_ub") { if (value < 1 || value > 3) return fail(YUE_ERR_ARG, "yue_set_option: scan_filter_ub must be 1, 2 or 3"); c->opt_scan_filter_ub = (int)value; return YUE_OK; }
     if (key == "scan_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(YUE_ERR_ARG, "yue_set_option: scan_growth must be 0 (automatic) or 2..64"); c->opt_scan_growth = (int)value; return YUE_OK; }
     if (key == "round_stage") {
         if (value < 0 || value > (int64_t)yue::kMetaStageMax) return fail(YUE_ERR_ARG, "yue_set_option: round_stage must be 0, 1 or 2..64");

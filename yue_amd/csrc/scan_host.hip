@@ -154,18 +154,21 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
                 if (!sa.mask_by_user) xa.mask_ptr = sa.mask_ptr + u0;
                 for (size_t q = 0; q + 1 < cb.size(); ++q) {
                     fa.item0 = xa.item0 = cb[q]; fa.item1 = xa.item1 = cb[q + 1];
-                    // scan_filter_ub: 2 = two blocks of 32 users per wave, 4 waves per workgroup (one item fragment read from LDS feeds two
-                    // MFMAs); 1 = one block per wave, 8 waves
-                    const int kUB = c->opt_scan_filter_ub == 1 ? 1 : 2, kFW = kUB == 2 ? 4 : 8;
+                    // scan_filter_ub: 3 = two blocks of 32 users per wave, 4 waves per workgroup, item rows by DMA into LDS (k = 64 / 128; other k: as 2);
+                    // 2 = the same blocking with rows staged through registers; 1 = one block per wave, 8 waves
+                    const int fmode = c->opt_scan_filter_ub == 3 && k != 64 && k != 128 ? 2 : c->opt_scan_filter_ub;
+                    const int kUB = fmode == 1 ? 1 : 2, kFW = kUB == 2 ? 4 : 8;
                     const int64_t ublocks = (un + 32 * kFW * kUB - 1) / (32 * kFW * kUB), iters = (cb[q + 1] - cb[q] + 63) / 64;
                     const int64_t splits = std::max<int64_t>(1, std::min<int64_t>(iters, (2 * cus + ublocks - 1) / ublocks));
                     fa.iters_per_block = ((iters + splits - 1) / splits + 15) / 16 * 16;      // a summary word (16 stages) belongs to one workgroup
                     const dim3 fgrid((unsigned)ublocks, (unsigned)((iters + fa.iters_per_block - 1) / fa.iters_per_block));
-                    const size_t flds = 2u * 64u * (size_t)(k + yue::kScanBfPad) * 2u;
-#define YUE_FILTER_V(K16_, FW_, UB_) do { if (settle) hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, true>), fgrid, dim3(64 * FW_), flds, c->stream, fa); \
-                                      else hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, false>), fgrid, dim3(64 * FW_), flds, c->stream, fa); } while (0)
-#define YUE_FILTER(K16_) do { if (kUB == 2) YUE_FILTER_V(K16_, 4, 2); else YUE_FILTER_V(K16_, 8, 1); } while (0)
-                    if (k == 16) YUE_FILTER(1); else if (k == 32) YUE_FILTER(2); else if (k == 64) YUE_FILTER(4); else YUE_FILTER(8);
+                    const size_t flds = yue::filter_lds_bytes(k);
+#define YUE_FILTER_V(K16_, FW_, UB_, DMA_) do { if (settle) hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, true, DMA_>), fgrid, dim3(64 * FW_), flds, c->stream, fa); \
+                                            else hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, false, DMA_>), fgrid, dim3(64 * FW_), flds, c->stream, fa); } while (0)
+#define YUE_FILTER(K16_) do { if (kUB == 2) YUE_FILTER_V(K16_, 4, 2, false); else YUE_FILTER_V(K16_, 8, 1, false); } while (0)
+#define YUE_FILTER_DMA(K16_) do { if (fmode == 3) YUE_FILTER_V(K16_, 4, 2, true); else YUE_FILTER(K16_); } while (0)
+                    if (k == 16) YUE_FILTER(1); else if (k == 32) YUE_FILTER(2); else if (k == 64) YUE_FILTER_DMA(4); else YUE_FILTER_DMA(8);
+#undef YUE_FILTER_DMA
 #undef YUE_FILTER
 #undef YUE_FILTER_V
                     hipLaunchKernelGGL((yue::k_scan_select<kSelWaves>), dim3((unsigned)((un + kSelWaves - 1) / kSelWaves)), dim3(64 * kSelWaves), sel_lds, c->stream, xa);

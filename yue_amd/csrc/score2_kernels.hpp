@@ -21,6 +21,12 @@
 
 namespace yue {
 
+// timing-only ablations of k_scan_filter (make EXTRA=-DYUE_FILTER_ABL=bits OBJDIR=build_fablN LIB=libyue_hip_fablN.so; lists WRONG by
+// construction): 1 no barrier between stages, 2 no sifting of the scores, 8 no item rows fetched / committed
+#ifndef YUE_FILTER_ABL
+#define YUE_FILTER_ABL 0
+#endif
+
 struct FilterArgs {
     const float *P;
     const __bf16 *Qb;            // item factors rounded to bf16, rows padded with zero rows to a multiple of 64
@@ -91,16 +97,29 @@ __global__ void __launch_bounds__(256) k_scan_scatter_rows(const int32_t *src_id
 // workgroups of four waves (the same 256 users per workgroup as UB = 1 with eight): 168 VGPRs = three waves per SIMD, one from
 // each of three workgroups, half the LDS reads and half the barriers per MFMA (config 5, factors of 25 epochs: 55 against 69 ms
 // per scan on the same box, the matrix pipe busy 64 % of the filter's cycles against 54 %; the shader clock falls to 1.7 GHz).
-template <int K16, int WAVES, int UB, bool SETTLE>
+//
+// DMA (UB = 2, four waves, k = 64 or 128): the item rows go from global memory straight into LDS (global_load_lds_dwordx4: no
+// staging registers, no ds_write; one wave-instruction fills 1 KB = 64 consecutive 16-byte pieces, so the rows lie unpadded and
+// the 16-byte column of a piece is XORed with a function of its row -- on the SOURCE address and again in the fragment reads --
+// which keeps ds_read_b128 free of bank conflicts).  (Tried with the freed registers: a whole tile's fragments resident and the
+// two user blocks one after the other, each block's scores sifted under the other's MFMAs -- 128 registers of fragments and
+// accumulators are live at the sift then, the compiler spills the user fragments inside the stage loop.)
+__host__ __device__ constexpr size_t filter_tile_bytes(int k) { return 2u * 64u * (size_t)(k + kScanBfPad) * 2u; }
+__host__ __device__ constexpr size_t filter_lds_bytes(int k) { return filter_tile_bytes(k) + 16u; }
+template <int K16, int WAVES, int UB, bool SETTLE, bool DMA = false>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(UB == 2 ? 3 : 2))) k_scan_filter(FilterArgs a) {
+    static_assert(!DMA || (UB == 2 && WAVES == 4 && (K16 == 4 || K16 == 8)), "the DMA form: two user blocks, four waves, k = 64 or 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int K = 16 * K16, LDB = K + kScanBfPad, NT = 64 * WAVES, ROWS = 64;
-    __bf16 *btile = reinterpret_cast<__bf16 *>(lds_raw);                 // [2][64][LDB]
-    __shared__ unsigned settled_waves;                                   // waves none of whose users can take a later item
+    __bf16 *btile = reinterpret_cast<__bf16 *>(lds_raw);                 // [2][64][LDB]   (DMA: [2][64][K], swizzled)
+    // waves none of whose users can take a later item: a word behind the tiles (a static __shared__ word would move the tiles off
+    // offset 0, and every fragment read of the DMA layout would pay an add beside its XOR)
+    unsigned &settled_waves = *reinterpret_cast<unsigned *>(lds_raw + filter_tile_bytes(K));
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     bool wave_settled = false;
     if (tid == 0) settled_waves = 0u;
+    if (DMA && (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw != 0u) __builtin_trap();     // (see frag() below)
     int64_t upos[UB];
     bool uvalid[UB];
     bf16x8 af[UB][K16];
@@ -124,7 +143,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     }
 
     // one stage = 64 consecutive rows of Qb = ROWS * K * 2 bytes, contiguous; 16-byte pieces
-    constexpr int PIECES = ROWS * K * 2 / 16, PF = (PIECES + NT - 1) / NT;
+    constexpr int PIECES = ROWS * K * 2 / 16, PF = DMA ? 1 : (PIECES + NT - 1) / NT;
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
     u32x4s pre[PF];
     int ldo[PF];
@@ -139,6 +158,26 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         __bf16 *dst = btile + stage * ROWS * LDB;
 #pragma unroll
         for (int q = 0; q < PF; ++q) if (PIECES % NT == 0 || tid + NT * q < PIECES) *reinterpret_cast<u32x4s *>(dst + ldo[q]) = pre[q];
+    };
+    // DMA: RB bytes per row, PR pieces per row; one instruction of a wave = 64 pieces = RPI rows; wave w fills rows 16 w .. 16 w + 15 of
+    // a stage with NI instructions.  Piece c of row y lies at column c ^ swz(y), swz(y) = y & 15 (k = 128: a row is the 256 bytes all
+    // 64 banks span) or (y >> 1) & 7 (k = 64: two rows per span): the 16 lanes ds_read_b128 serves together (rows 0-3, 12-15 and 20-27
+    // of a tile, one column) then fall on 16 different 16-byte slots of the span.
+    constexpr int RB = K * 2, PR = K / 8, RPI = 64 / PR, NI = 16 / RPI;
+    auto swz = [](int y) { return K16 == 8 ? (y & 15) : ((y >> 1) & 7); };
+    // (byte offset of lane's piece in instruction i: row 16 w + RPI i + lane / PR, column (lane % PR) ^ swz(row); swz(row) = 4 i | lane / 16
+    // in both layouts, so instruction i differs from instruction 0 by an XOR of 64 i in the column field and 1024 i bytes of rows)
+    const unsigned dma_off0 = DMA ? (unsigned)((16 * w + lane / PR) * RB + (((lane % PR) ^ (lane >> 4)) << 4)) : 0u;
+    // (buffer_load ... lds rather than global_load_lds: behind a FLAT-encoded load that may touch LDS the compiler's wait insertion
+    // turns every later lgkmcnt wait into lgkmcnt(0) until the load itself has been waited for -- the ring below would lose its depth)
+    const auto rsQb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(a.Qb), 0, (int)(((a.n + 63) / 64 * 64) * K * 2), 0x00020000);
+    auto dma = [&](int64_t it0, int stage) {
+        unsigned off0 = dma_off0;
+        asm volatile("" : "+v"(off0));                         // (recomputed per stage: hoisted per-instruction offsets would cost registers)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQb, (__attribute__((address_space(3))) void *)(lds_raw + (stage * ROWS + 16 * w + RPI * i) * RB), 16,
+                                                     (int)((off0 ^ (64u * i)) + 1024u * i), (int)(it0 * K * 2), 0, 0);
     };
 
     const int64_t niter_all = (a.item1 - a.item0 + ROWS - 1) / ROWS;
@@ -155,9 +194,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         const int64_t i0 = a.item0 + it_begin * ROWS;
         nu0_next = a.tile_norm_max[i0 / kScanTile]; nu1_next = (i0 + kScanTile < a.n) ? a.tile_norm_max[i0 / kScanTile + 1] : 0.0f;
     }
-    fetch(a.item0 + it_begin * ROWS);
-    commit((int)(it_begin & 1));
-    __syncthreads();
+    if (DMA) dma(a.item0 + it_begin * ROWS, (int)(it_begin & 1));
+    else { fetch(a.item0 + it_begin * ROWS); commit((int)(it_begin & 1)); }
+    __syncthreads();                                         // (with a DMA in flight the compiler's barrier waits for it: vmcnt(0))
     for (int64_t it = it_begin; it < niter; ++it) {
         const int stage = (int)(it & 1);
         const int64_t it0 = a.item0 + it * ROWS;
@@ -194,7 +233,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         if (it + 1 < niter) {
             const int64_t tn = (it0 + ROWS) / kScanTile;
             nu0_next = a.tile_norm_max[tn]; nu1_next = (it0 + ROWS + kScanTile < a.n) ? a.tile_norm_max[tn + 1] : 0.0f;
-            fetch(it0 + ROWS);
+            if (!(YUE_FILTER_ABL & 8)) { if (DMA) dma(it0 + ROWS, stage ^ 1); else fetch(it0 + ROWS); }
         }
         bool settled = true;                                 // Cauchy-Schwarz: no exact score of these tiles reaches the threshold
 #pragma unroll
@@ -203,6 +242,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             tiles_done += 2 * UB;
             uint32_t pm[UB][2];
             auto sift = [&](const f32x16 &sc, int b, int q) {
+                if (YUE_FILTER_ABL & 2) { asm volatile("" :: "v"(sc)); pm[b][q] = 0u; return; }
                 const float bar = thr[b] - mu[b] * (q ? nu1 : nu0);
                 // most tiles hold no survivor for any user of the wave: one max over the lane's 16 scores decides that
                 float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
@@ -225,7 +265,17 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             // accumulators (af[2][K16] + two generations would not leave three waves per SIMD).
             constexpr int J = 2 * K16, RD = J < 4 ? J : 4, SIFT0 = UB == 1 ? (K16 + 2 < J ? K16 + 2 : J - 1) : K16 - 1;
             const __bf16 *irow = tbb + r * LDB + 8 * h;
-            auto frag = [&](int j) { return *reinterpret_cast<const bf16x8 *>(irow + (j / K16) * kScanTile * LDB + 16 * (j % K16)); };
+            // DMA layout: column 2 s + h of row r lies at ((2 s) ^ h ^ swz(r)) * 16 -- stage, row and column are separate bit fields of
+            // the offset: one XOR per k-step and stage (K16 addresses, the second tile's reads add 32 rows in the instruction).  The
+            // offset is an LDS address as it stands (the tiles begin at LDS address 0: no static __shared__ in this kernel) and passes
+            // through an empty statement once per stage (addresses hoisted out of the stage loop for both stages would cost registers).
+            typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
+            unsigned frag0 = (unsigned)(stage * ROWS * RB + r * RB) | (unsigned)((h ^ swz(r)) << 4);
+            if (DMA) asm volatile("" : "+v"(frag0));
+            auto frag = [&](int j) {
+                if constexpr (DMA) return *reinterpret_cast<lds_frag_ptr>((frag0 ^ (32u * (j % K16))) + (j / K16) * kScanTile * RB);
+                else return *reinterpret_cast<const bf16x8 *>(irow + (j / K16) * kScanTile * LDB + 16 * (j % K16));
+            };
             bf16x8 ring[RD];
 #pragma unroll
             for (int j = 0; j < RD - 1; ++j) ring[j] = frag(j);
@@ -272,8 +322,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 summ[b] = 0u;
             }
         }
-        if (it + 1 < niter) commit(stage ^ 1);
-        __syncthreads();
+        if (!DMA && it + 1 < niter && !(YUE_FILTER_ABL & 8)) commit(stage ^ 1);
+        if (!(YUE_FILTER_ABL & 1)) __syncthreads();
     }
     if (lane == 0) atomicAdd(work_slot(a.work, (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + w), (unsigned long long)tiles_done);
 }
