@@ -182,6 +182,11 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *               fused kernel for everything (same lists and scores)
  *   "scan_growth" 0 (default): each chunk of the two-phase scan ends at 2x or 8x the items scanned so far, chosen from the
  *               list-update rate of the first 512 items; 2..64: that factor
+ *   "scan_filter_ub" form of k_scan_filter: 3 (default) = two blocks of 32 users per wave in workgroups of four waves, item rows by
+ *               LDS-DMA (k = 64 / 128; other k: as 2); 2 = the same blocking, rows staged through registers; 1 = one block per
+ *               wave, eight waves (round 3).  Same lists and scores
+ *   "scan_streams" 2 (default): calls of at least "scan_streams_min_users" users (262,144) split them into four or more slabs that
+ *               alternate between two streams -- one slab's selection beside the next slab's filter; 1: one stream
  *   "fism_lds"   1 (default): yue_fism_rounds keeps a user's working rows in LDS when they fit (k_fism_round_lds); 0: always the
  *               form with working rows in global memory and host-built item lists
  *   "chain_waves" exact path: workgroups per CU of the dataflow launch, 1..8 (0 = default: 1; 2 with chain_xcd)

@@ -319,6 +319,31 @@ def test_two_phase_scan_with_settled_users(dev, orc, m, n, k, N, form):
     assert np.array_equal(ids, ids_f) and np.array_equal(sc, sc_f)
 
 
+def test_two_phase_scan_with_slabs_on_two_streams(dev, orc):
+    """Calls with many users split them into four or more slabs that alternate between two streams (a slab's selection beside the
+    next slab's filter, each stream with its own survivor words).  Here the user count that switches this on is lowered: 3,000
+    users = 4 slabs of 768 (the last one short); lists and scores must equal the one-stream run and the oracle."""
+    m, n, k, N = 3000, 20000, 128, 20
+    P, Q, indptr, indices = _rand_problem(m, n, k, 25, seed=77, signed=True)
+    users = np.arange(m, dtype=np.int32)
+    mp, mi = mask_rows(indptr, indices, users)
+    dev.set_factors(P, Q)
+    dev.set_option('scan_streams_min_users', 1024)
+    try:
+        ids, sc = dev.topn_scan(users, N, mp, mi)
+        assert dev.get_option('scan_last_chunks') >= 2
+        dev.set_option('scan_streams', 1)
+        ids1, sc1 = dev.topn_scan(users, N, mp, mi)
+    finally:
+        dev.set_option('scan_streams', 2)
+        dev.set_option('scan_streams_min_users', 262144)
+    assert np.array_equal(ids, ids1) and np.array_equal(sc, sc1)
+    sample = np.arange(0, m, 7, dtype=np.int32)
+    smp, smi = mask_rows(indptr, indices, sample)
+    oid, osc, rc = orc.topn_scan(P, Q, sample, N, smp, smi)
+    assert np.array_equal(ids[sample], oid) and np.array_equal(sc[sample], osc)
+
+
 def test_two_phase_scan_with_a_heavy_listener_of_the_catalogues_head(dev, orc):
     """A few users have listened to almost all of the first 512 items: their first chunk holds fewer than N candidates.  Only they
     go through the fused kernel over all items (option-free: scan_last_few_users says how many), everybody else through the

@@ -37,7 +37,8 @@ scan)
         PROBE_DEFAULT=1 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d gpurun_out/pm/${tag}_scan_sq_$ep -- python3 tools/scan_probe.py $ep > gpurun_out/pm/${tag}_scan_sq_$ep.log 2>&1 && python tools/pmc_summary.py gpurun_out/pm/${tag}_scan_sq_$ep > gpurun_out/pm/${tag}_scan_sq_$ep.txt && rm -rf gpurun_out/pm/${tag}_scan_sq_$ep && echo "scan SQ pass ($ep epochs) done"
         PROBE_DEFAULT=1 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pm/${tag}_scan_gui_$ep -- python3 tools/scan_probe.py $ep > gpurun_out/pm/${tag}_scan_gui_$ep.log 2>&1 && python tools/pmc_summary.py gpurun_out/pm/${tag}_scan_gui_$ep > gpurun_out/pm/${tag}_scan_gui_$ep.txt && rm -rf gpurun_out/pm/${tag}_scan_gui_$ep && echo "scan GUI pass ($ep epochs) done"
         grep "epochs," gpurun_out/pm/${tag}_scan_gui_$ep.log
-    done ;;
+    done
+    PROBE_DEFAULT=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks -- python3 tools/scan_probe.py 25 > $out/ks.log 2>&1 && cp $(find $out/ks -name '*kernel_stats.csv' | head -1) $out/scan_25epochs_kernel_stats.csv && rm -rf $out/ks && echo "scan kernel stats (25 epochs) done" ;;
 exact)
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kx -- python3 tools/exact_probe.py c3 2 > $out/kx.log 2>&1 && cp $(find $out/kx -name '*kernel_stats.csv' | head -1) $out/exact_c3_kernel_stats.csv && rm -rf $out/kx && echo exact kernel stats ok ;;
 *) echo "unknown stage $st" ;;

@@ -31,7 +31,7 @@ users = np.arange(nu, dtype=np.int32)
 ref = None
 configs = [('default (two-phase, growth chosen from the first chunk)', {'scan_filter_ub': int(os.environ['PROBE_FORM'])} if os.environ.get('PROBE_FORM') else {})] if os.environ.get('PROBE_DEFAULT') else None
 if os.environ.get('PROBE_UB'):          # one or two blocks of users per filter wave
-    configs = [('two-phase, filter form %d' % v, {'scan_filter_ub': v}) for v in (2, 3, 2, 3)]
+    configs = [('two-phase, %d stream(s), %d slabs' % (t, sl), {'scan_streams': t, 'scan_slabs': sl}) for t, sl in ((1, 4), (2, 2), (2, 4), (2, 6), (2, 8), (2, 12), (2, 4))]
 for label, opts in configs or [('fused', {'scan_two_phase': 0}), ('two-phase x2', {'scan_two_phase': 1, 'scan_growth': 2}), ('two-phase x4', {'scan_two_phase': 1, 'scan_growth': 4}),
                     ('two-phase x8', {'scan_two_phase': 1, 'scan_growth': 8}), ('two-phase x16', {'scan_two_phase': 1, 'scan_growth': 16})]:
     for a, b in opts.items():

@@ -795,6 +795,9 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "fism_lds") *value = c->opt_fism_lds;
     else if (key == "scan_growth") *value = c->opt_scan_growth;
     else if (key == "scan_filter_ub") *value = c->opt_scan_filter_ub;
+    else if (key == "scan_streams") *value = c->opt_scan_streams;
+    else if (key == "scan_slabs") *value = c->opt_scan_slabs;
+    else if (key == "scan_streams_min_users") *value = c->opt_scan_streams_min_users;
     else if (key == "scan_last_chunks") *value = c->scan_chunks;
     else if (key == "scan_last_few_users") *value = c->scan_few_users;
     else if (key == "scan_last_settle") *value = c->scan_settle;
@@ -837,6 +840,9 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "scan_two_phase") { c->opt_scan_two_phase = value != 0; return YUE_OK; }
     if (key == "fism_lds") { c->opt_fism_lds = value != 0; return YUE_OK; }
+    if (key == "scan_streams_min_users") { if (value < 1024) return fail(YUE_ERR_ARG, "yue_set_option: scan_streams_min_users must be at least 1024"); c->opt_scan_streams_min_users = value; return YUE_OK; }
+    if (key == "scan_slabs") { if (value < 2 || value > 64) return fail(YUE_ERR_ARG, "yue_set_option: scan_slabs must be 2..64"); c->opt_scan_slabs = (int)value; return YUE_OK; }
+    if (key == "scan_streams") { if (value != 1 && value != 2) return fail(YUE_ERR_ARG, "yue_set_option: scan_streams must be 1 or 2"); c->opt_scan_streams = (int)value; return YUE_OK; }
     if (key == "scan_filter_ub") { if (value < 1 || value > 3) return fail(YUE_ERR_ARG, "yue_set_option: scan_filter_ub must be 1, 2 or 3"); c->opt_scan_filter_ub = (int)value; return YUE_OK; }
     if (key == "scan_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(YUE_ERR_ARG, "yue_set_option: scan_growth must be 0 (automatic) or 2..64"); c->opt_scan_growth = (int)value; return YUE_OK; }
     if (key == "round_stage") {

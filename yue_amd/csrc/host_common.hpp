@@ -100,6 +100,9 @@ struct yue_ctx {
     DevBuf<unsigned short> s_qb;         // two-phase scoring: bf16 copy of the item factors
     DevBuf<uint32_t> s_masks;            // ... and the survivor words of a chunk
     int opt_scan_two_phase = 1;          // 0: always the fused kernels (k_topn_scan*)
+    int64_t opt_scan_streams_min_users = 262144;   // ... from this many users of a call on (tests lower it)
+    int opt_scan_slabs = 4;              // ... slabs of users at least, with two streams
+    int opt_scan_streams = 2;            // two-phase path, 262,144 users and more: slabs of users alternate between two streams (1: one stream)
     int opt_scan_filter_ub = 3;          // two-phase path: form of k_scan_filter (scan_host.hip): 3 = two blocks of 32 users per wave, rows by DMA into LDS; 2 = rows through registers; 1 = one block, 8 waves
     int opt_scan_growth = 0;             // two-phase path: a chunk ends at this many times the items scanned so far (0: 2 or 8 by the first items' update rate)
     int scan_chunks = 0;                 // chunks the last scan ran through the filter / select pair

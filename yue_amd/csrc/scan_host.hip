@@ -132,22 +132,32 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
             while (cb.back() < c->n) cb.push_back(std::min<int64_t>(c->n, cb.back() * growth));
             int64_t stride = 2;
             for (size_t q = 0; q + 1 < cb.size(); ++q) stride = std::max<int64_t>(stride, ((cb[q + 1] - cb[q] + 127) / 128) * 4);
-            // users in slabs, so that the survivor words of a chunk stay below 12 GB
-            const int64_t slab = std::max<int64_t>(256, std::min<int64_t>(nu, ((12ll << 30) / (stride * 4)) / 256 * 256));
+            // users in slabs, so that the survivor words of a chunk stay below 12 GB -- and, for many users, at least four slabs that
+            // alternate between two streams (each with its own survivor words): the selection of one slab (row gathers, HBM-bound)
+            // runs beside the filter of the next (MFMA-bound); a slab's own chunks stay in order on its stream
+            const int lanes = (c->opt_scan_streams >= 2 && nu >= c->opt_scan_streams_min_users) ? 2 : 1;
+            int64_t slab = std::max<int64_t>(256, std::min<int64_t>(nu, ((12ll << 30) / (stride * 4)) / 256 * 256));
+            if (lanes == 2) slab = std::min<int64_t>(slab, ((nu + c->opt_scan_slabs - 1) / c->opt_scan_slabs + 255) / 256 * 256);
             const int64_t sstride = (stride + 31) / 32 + 1;
-            HIPCHK(c->s_masks.resize((size_t)(std::min(slab, nu) * (stride + sstride))));
-            uint32_t *summary = c->s_masks.p + std::min(slab, nu) * stride;
+            const int64_t lane_words = std::min(slab, nu) * (stride + sstride);
+            HIPCHK(c->s_masks.resize((size_t)(lanes * lane_words)));
             yue::FilterArgs fa{};
             fa.P = c->P.p; fa.Qb = reinterpret_cast<const __bf16 *>(c->s_qb.p); fa.N = N; fa.tile_norm_max = c->s_norms.p; fa.tile_norm_sufmax = c->s_norms.p + ntile; fa.masks = c->s_masks.p;
-            fa.mask_stride = stride; fa.work = c->s_work.p; fa.n = c->n; fa.summary = summary; fa.sum_stride = sstride;
+            fa.mask_stride = stride; fa.work = c->s_work.p; fa.n = c->n; fa.sum_stride = sstride;
             yue::SelectArgs xa{};
             xa.P = c->P.p; xa.Q = c->Q.p; xa.n = c->n; xa.k = k; xa.N = N; xa.mask_ptr = sa.mask_ptr; xa.mask_idx = sa.mask_idx; xa.mask_by_user = sa.mask_by_user;
-            xa.masks = c->s_masks.p; xa.mask_stride = stride; xa.summary = summary; xa.sum_stride = sstride; xa.work = c->s_work.p; xa.true_topn = c->opt_topn_true;
+            xa.mask_stride = stride; xa.sum_stride = sstride; xa.work = c->s_work.p; xa.true_topn = c->opt_topn_true;
             constexpr int kSelWaves = 2;
             const size_t sel_lds = yue::select_lds_bytes(kSelWaves);
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&yue::k_scan_select<kSelWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-            for (int64_t u0 = 0; u0 < nu; u0 += slab) {
+            if (lanes == 2) { HIPCHK(hipEventRecord(c->ev_rounds, c->stream)); HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_rounds, 0)); }
+            int64_t slab_ix = 0;
+            for (int64_t u0 = 0; u0 < nu; u0 += slab, ++slab_ix) {
                 const int64_t un = std::min(slab, nu - u0);
+                const int ln = lanes == 2 ? (int)(slab_ix & 1) : 0;
+                hipStream_t st = ln ? c->comm_stream : c->stream;
+                xa.masks = fa.masks = c->s_masks.p + ln * lane_words;
+                xa.summary = fa.summary = c->s_masks.p + ln * lane_words + std::min(slab, nu) * stride;
                 fa.users = c->s_users.p + u0; fa.nu = un; fa.thr_rows = c->s_scores.p + u0 * N;
                 xa.users = c->s_users.p + u0; xa.nu = un; xa.ids = c->s_ids.p + u0 * N; xa.scores = c->s_scores.p + u0 * N;
                 // (an explicit mask is indexed by position in users[]: shift its row pointer with the slab)
@@ -163,18 +173,19 @@ int yue_topn_scan(yue_ctx *c, const int32_t *users, int64_t nu, int N, const int
                     fa.iters_per_block = ((iters + splits - 1) / splits + 15) / 16 * 16;      // a summary word (16 stages) belongs to one workgroup
                     const dim3 fgrid((unsigned)ublocks, (unsigned)((iters + fa.iters_per_block - 1) / fa.iters_per_block));
                     const size_t flds = yue::filter_lds_bytes(k);
-#define YUE_FILTER_V(K16_, FW_, UB_, DMA_) do { if (settle) hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, true, DMA_>), fgrid, dim3(64 * FW_), flds, c->stream, fa); \
-                                            else hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, false, DMA_>), fgrid, dim3(64 * FW_), flds, c->stream, fa); } while (0)
+#define YUE_FILTER_V(K16_, FW_, UB_, DMA_) do { if (settle) hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, true, DMA_>), fgrid, dim3(64 * FW_), flds, st, fa); \
+                                            else hipLaunchKernelGGL((yue::k_scan_filter<K16_, FW_, UB_, false, DMA_>), fgrid, dim3(64 * FW_), flds, st, fa); } while (0)
 #define YUE_FILTER(K16_) do { if (kUB == 2) YUE_FILTER_V(K16_, 4, 2, false); else YUE_FILTER_V(K16_, 8, 1, false); } while (0)
 #define YUE_FILTER_DMA(K16_) do { if (fmode == 3) YUE_FILTER_V(K16_, 4, 2, true); else YUE_FILTER(K16_); } while (0)
                     if (k == 16) YUE_FILTER(1); else if (k == 32) YUE_FILTER(2); else if (k == 64) YUE_FILTER_DMA(4); else YUE_FILTER_DMA(8);
 #undef YUE_FILTER_DMA
 #undef YUE_FILTER
 #undef YUE_FILTER_V
-                    hipLaunchKernelGGL((yue::k_scan_select<kSelWaves>), dim3((unsigned)((un + kSelWaves - 1) / kSelWaves)), dim3(64 * kSelWaves), sel_lds, c->stream, xa);
+                    hipLaunchKernelGGL((yue::k_scan_select<kSelWaves>), dim3((unsigned)((un + kSelWaves - 1) / kSelWaves)), dim3(64 * kSelWaves), sel_lds, st, xa);
                     if (u0 == 0) c->scan_chunks++;
                 }
             }
+            if (lanes == 2) { HIPCHK(hipEventRecord(c->ev_comm, c->comm_stream)); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm, 0)); }
             if (nfew > 0) {      // the few-candidates users: the fused kernel over all items, rows back to their places
                 HIPCHK(c->s_few_ids.resize((size_t)(nfew * N))); HIPCHK(c->s_few_scores.resize((size_t)(nfew * N)));
                 yue::ScanArgs sf = sa;
