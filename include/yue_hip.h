@@ -189,6 +189,9 @@ int yue_get_scan_work(yue_ctx *ctx, int64_t *tiles_scored, int64_t *tiles_total)
  *               alternate between two streams -- one slab's selection beside the next slab's filter; 1: one stream
  *   "fism_lds"   1 (default): yue_fism_rounds keeps a user's working rows in LDS when they fit (k_fism_round_lds); 0: always the
  *               form with working rows in global memory and host-built item lists
+ *   "fism_inplace" 1 (default): in k_fism_round_lds a row only ONE user of the round touches goes back to the model in place
+ *               (no second read of the round-start row, no atomic adds; the round in front counts the users per row);
+ *               0: every row through the difference buffers
  *   "chain_waves" exact path: workgroups per CU of the dataflow launch, 1..8 (0 = default: 1; 2 with chain_xcd)
  *   "chain_split" exact path: 1 = a run is walked by a GROUP of five waves (k_bpr_chain3: two keep the memory side -- headers,
  *               prefetch rings, version checks, polling; even / odd triplets --, one the dependency chain margin -> sigmoid ->

@@ -178,7 +178,9 @@ def test_through_the_plugin_surface(tmp_path, capsys):
 @pytest.mark.parametrize('k', [64, 130, 10])
 def test_rounds_with_working_rows_in_lds_equal_the_global_form(dev, k):
     # users of at most 64 touches take k_fism_round_lds (the wave finds its rows itself, working copies in LDS): same pass as
-    # k_fism_round (option fism_lds = 0) and as the NumPy oracle; ragged users, duplicates inside a user, repeated negatives
+    # k_fism_round (option fism_lds = 0) and as the NumPy oracle; ragged users, duplicates inside a user, repeated negatives;
+    # with and without the rows only one user of a round touches stored in place (option fism_inplace: one user per round =
+    # every row in place, 5 = some of them, 100 = the users of the whole problem share most rows)
     from oracle.numpy_fism import fism_rounds
     rng = np.random.RandomState(11 + k)
     n, rho, alpha = 50, 3, 0.5
@@ -194,14 +196,16 @@ def test_rounds_with_working_rows_in_lds_equal_the_global_form(dev, k):
     P0, Q0, B0 = rng.rand(n, k) / 100, (rng.rand(n, k) / 10).astype(np.float32), rng.rand(n) / 100
     for round_users in (1, 5, 100):
         res = []
-        for lds in (1, 0):
+        for lds, inplace in ((1, 1), (1, 0), (0, 1)):
             dev.set_option('fism_lds', lds)
+            dev.set_option('fism_inplace', inplace)
             dev.fism_set_model(P0, Q0, B0)
             half, _, _, _ = dev.fism_rounds(ptr, ev_i, negs, rho, coefs(ptr, alpha), round_users, 0.02, 0.01, 0.03)
             P, Q, Bi = np.empty_like(P0), np.empty_like(Q0), np.empty_like(B0)
             dev.fism_get_model(P, Q, Bi)
             res.append((half, P, Q, Bi))
         dev.set_option('fism_lds', 1)
+        dev.set_option('fism_inplace', 1)
         Po, Qo, Bo = P0.copy(), Q0.copy(), B0.copy()
         half_o = fism_rounds(Po, Qo, Bo, ptr, ev_i, negs, rho, alpha, 0.02, 0.01, 0.03, round_users)
         for half, P, Q, Bi in res:

@@ -793,6 +793,7 @@ int yue_get_option(yue_ctx *c, const char *name, int64_t *value) {
     else if (key == "scan_batch") *value = c->opt_scan_batch;
     else if (key == "scan_two_phase") *value = c->opt_scan_two_phase;
     else if (key == "fism_lds") *value = c->opt_fism_lds;
+    else if (key == "fism_inplace") *value = c->opt_fism_inplace;
     else if (key == "scan_growth") *value = c->opt_scan_growth;
     else if (key == "scan_filter_ub") *value = c->opt_scan_filter_ub;
     else if (key == "scan_streams") *value = c->opt_scan_streams;
@@ -840,6 +841,7 @@ int yue_set_option(yue_ctx *c, const char *name, int64_t value) {
     if (key == "topn_true") { c->opt_topn_true = value != 0; return YUE_OK; }
     if (key == "scan_two_phase") { c->opt_scan_two_phase = value != 0; return YUE_OK; }
     if (key == "fism_lds") { c->opt_fism_lds = value != 0; return YUE_OK; }
+    if (key == "fism_inplace") { c->opt_fism_inplace = value != 0; return YUE_OK; }
     if (key == "scan_streams_min_users") { if (value < 1024) return fail(YUE_ERR_ARG, "yue_set_option: scan_streams_min_users must be at least 1024"); c->opt_scan_streams_min_users = value; return YUE_OK; }
     if (key == "scan_slabs") { if (value < 2 || value > 64) return fail(YUE_ERR_ARG, "yue_set_option: scan_slabs must be 2..64"); c->opt_scan_slabs = (int)value; return YUE_OK; }
     if (key == "scan_streams") { if (value != 1 && value != 2) return fail(YUE_ERR_ARG, "yue_set_option: scan_streams must be 1 or 2"); c->opt_scan_streams = (int)value; return YUE_OK; }

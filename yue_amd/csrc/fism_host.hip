@@ -124,12 +124,23 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
             a.lr = lr; a.regI = regI; a.regB = regB; a.x_rows = c->f_x.p; a.out = sc;
             yue::FismLdsArgs la{};
             la.neg_ptr = c->f_neg_ptr.p; la.dQ = c->f_dQ.p; la.dP = c->f_dP.p; la.dB = c->f_dB.p; la.rows_cap = (int)cnt_max;
+            // rows one user of a round has to itself go back in place (option fism_inplace, default 1): two count arrays, swapped per round
+            unsigned *cnt[2] = {nullptr, nullptr};
+            if (c->opt_fism_inplace) {
+                HIPCHK(c->f_cnt.resize(2 * (size_t)c->fn));
+                HIPCHK(hipMemsetAsync(c->f_cnt.p, 0, 2 * (size_t)c->fn * sizeof(unsigned), c->stream));
+                cnt[0] = c->f_cnt.p; cnt[1] = c->f_cnt.p + c->fn;
+                hipLaunchKernelGGL(yue::k_fism_count_round, dim3((unsigned)std::min(m, round_users)), dim3(64), 0, c->stream, a, la.neg_ptr, (int64_t)0, std::min(m, round_users), cnt[0]);
+            }
             const void *kfn = kr_of(c->fk) == 1 ? (const void *)yue::k_fism_round_lds<1> : kr_of(c->fk) == 2 ? (const void *)yue::k_fism_round_lds<2> : (const void *)yue::k_fism_round_lds<4>;
             HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const dim3 apply_grid((unsigned)std::min<int64_t>(1024, (int64_t)(nk + 255) / 256));
             for (int64_t u0 = 0; u0 < m; u0 += round_users) {
                 const int64_t u1 = std::min(m, u0 + round_users);
                 la.u_begin = u0; la.u_end = u1;
+                const int par = (int)((u0 / round_users) & 1);
+                la.cnt_cur_r = la.cnt_cur = cnt[par]; la.cnt_next = cnt[par ^ 1];
+                la.next_begin = u1; la.next_end = std::min(m, u1 + round_users);
                 const dim3 grid((unsigned)(u1 - u0));
                 switch (kr_of(c->fk)) {
                     case 1: hipLaunchKernelGGL(yue::k_fism_round_lds<1>, grid, dim3(64), lds, c->stream, a, la); break;

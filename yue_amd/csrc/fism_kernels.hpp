@@ -35,10 +35,33 @@ struct FismArgs {
     double *out;                 // out[0] = sum of 0.5 * error^2
 };
 
+// Sum over the 64 lanes, the butterfly with partners lane^1, ^2, ^4, ^8, ^16, ^32 (the order round 2's __shfl_xor loop had:
+// same operands per step, so the same double on every lane), without its twelve trips through the LDS crossbar: DPP moves of
+// the two halves for the first four steps (quad_perm, quad_perm, row_half_mirror, row_mirror: the value is already constant over
+// the smaller groups), v_permlane16_swap of the value with itself for ^16, lanes 0 and 32 for ^32.  The two sums of a draw sit
+// in the dependency chain of every draw of every user.
+template <int CTRL>
+__device__ __forceinline__ double fism_dpp_mov(double v) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off);
-    return v;
+    v = v + fism_dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = v + fism_dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + fism_dpp_mov<0x141>(v);      // row_half_mirror
+    v = v + fism_dpp_mov<0x140>(v);      // row_mirror
+    {   // rows 0, 0, 2, 2 in one result and 1, 1, 3, 3 in the other (see wave_sum of bpr_device.hpp for the s_nops)
+        const uint64_t b = __builtin_bit_cast(uint64_t, v);
+        uint32_t lo0 = (uint32_t)b, lo1 = lo0, hi0 = (uint32_t)(b >> 32), hi1 = hi0;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(lo0), "+v"(lo1), "+v"(hi0), "+v"(hi1));
+        v = __builtin_bit_cast(double, ((uint64_t)hi0 << 32) | lo0) + __builtin_bit_cast(double, ((uint64_t)hi1 << 32) | lo1);
+    }
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint64_t t0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 0);
+    const uint64_t t1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 32) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 32);
+    return __builtin_bit_cast(double, t0) + __builtin_bit_cast(double, t1);
 }
 
 // Loads / stores that go to L2 (sc1): the wave re-reads rows it has just rewritten, the L1 must not
@@ -282,12 +305,39 @@ struct FismLdsArgs {
     float *dQ;
     double *dP, *dB;
     int rows_cap;                    // working rows a user may need (<= 64)
+    // Rows only ONE user of the round touches (round 4): that user's wave stores its working row in place -- no round-start
+    // row read again, no atomic adds, nothing for k_fism_apply to fold.  cnt_cur[item] = users of THIS round touching the item
+    // (null: every row goes through the difference buffers, round 3's form); the waves of a round count the NEXT round's
+    // users into cnt_next (block b: user next_begin + b) and clear their own entries of cnt_cur behind them -- the two
+    // arrays swap per round; a wave that reads an entry another wave has already cleared sees 0 instead of >= 2: shared either way.
+    const unsigned *cnt_cur_r;
+    unsigned *cnt_cur, *cnt_next;
+    int64_t next_begin, next_end;
 };
+
+// the distinct items user u touches (its events' items and its negatives), each counted once into cnt
+__device__ __forceinline__ void fism_count_rows(const FismArgs &a, const int64_t *neg_ptr, int64_t u, unsigned *cnt, int lane) {
+    const int64_t e0 = a.user_ptr[u], e1 = a.user_ptr[u + 1];
+    const int ne = (int)(e1 - e0);
+    if (ne <= 1) return;
+    const int c = ne + ne * a.rho;
+    const int64_t n0 = neg_ptr[u];
+    const int32_t x = lane < ne ? a.ev_i[e0 + lane] : lane < c ? a.negs[n0 + lane - ne] : -1;
+    bool first = lane < c;
+    for (int t = 0; t < c; ++t) { const int32_t xt = __builtin_amdgcn_readlane(x, t); if (x == xt && t < lane) first = false; }
+    if (first) atomicAdd(cnt + x, 1u);
+}
+// before the first round of a call: its users' rows counted (later rounds are counted by the round in front of them)
+__global__ void __launch_bounds__(64) k_fism_count_round(FismArgs a, const int64_t *neg_ptr, int64_t u_begin, int64_t u_end, unsigned *cnt) {
+    const int64_t u = u_begin + blockIdx.x;
+    if (u < u_end) fism_count_rows(a, neg_ptr, u, cnt, threadIdx.x);
+}
 
 template <int KR>
 __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fism_lds[];
     const int lane = threadIdx.x;
+    if (ra.cnt_next && ra.next_begin + blockIdx.x < ra.next_end) fism_count_rows(a, ra.neg_ptr, ra.next_begin + blockIdx.x, ra.cnt_next, lane);
     const int64_t u = ra.u_begin + blockIdx.x;
     if (u >= ra.u_end) return;
     const int k = a.k;
@@ -306,6 +356,8 @@ __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs r
     const unsigned long long fmask = __ballot(lane < cnt && first == lane);
     const int urow = __popcll(fmask & ((1ull << first) - 1ull));                    // the item's working row
     const int nuniq = __popcll(fmask);
+    // rows of mine nobody else in the round touches
+    const unsigned long long emask = __ballot(ra.cnt_cur_r && lane < cnt && first == lane && ra.cnt_cur_r[x] == 1u);
     {   // copy in the rows this user touches, eight rows' loads in flight at a time
         unsigned long long mleft = fmask;
         for (int s0 = 0; s0 < nuniq; s0 += 8) {
@@ -401,19 +453,21 @@ __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs r
             if (el < k) { const double p = wp[s * k + el]; wp[s * k + el] = p + a.lr * (pc * xr[(int64_t)e * k + el] - a.regI * p); }
         }
     }
-    {   // what this user changed: working row - round-start row, added to the round's difference buffers (the round-start rows
-        // again eight at a time)
+    {   // what this user changed: a row of its own goes back in place; of a shared row, working row - round-start row is added
+        // to the round's difference buffers (the round-start rows again eight at a time)
         unsigned long long mleft = fmask;
         for (int s0 = 0; s0 < nuniq; s0 += 8) {
             int64_t it[8];
             float q[8][KR];
             double p[8][KR], b[8];
+            bool own[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int src = mleft ? __ffsll((long long)mleft) - 1 : 0;
                 mleft &= mleft - 1;
                 it[t] = __builtin_amdgcn_readlane(x, src);
-                const bool ex = s0 + t < nuniq;
+                own[t] = (emask >> src) & 1ull;
+                const bool ex = s0 + t < nuniq && !own[t];
 #pragma unroll
                 for (int r = 0; r < KR; ++r) {
                     const int el = 64 * r + lane;
@@ -429,17 +483,24 @@ __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs r
                     for (int r = 0; r < KR; ++r) {
                         const int el = 64 * r + lane;
                         if (el < k) {
-                            const float dq = wq[(s0 + t) * k + el] - q[t][r];
-                            if (dq != 0.0f) atomicAdd(ra.dQ + it[t] * k + el, dq);
-                            const double dp = wp[(s0 + t) * k + el] - p[t][r];
-                            if (dp != 0.0) atomicAdd(ra.dP + it[t] * k + el, dp);
+                            if (own[t]) { a.Q[it[t] * k + el] = wq[(s0 + t) * k + el]; a.P[it[t] * k + el] = wp[(s0 + t) * k + el]; }
+                            else {
+                                const float dq = wq[(s0 + t) * k + el] - q[t][r];
+                                if (dq != 0.0f) atomicAdd(ra.dQ + it[t] * k + el, dq);
+                                const double dp = wp[(s0 + t) * k + el] - p[t][r];
+                                if (dp != 0.0) atomicAdd(ra.dP + it[t] * k + el, dp);
+                            }
                         }
                     }
-                    if (lane == 0) { const double db = wb[s0 + t] - b[t]; if (db != 0.0) atomicAdd(ra.dB + it[t], db); }
+                    if (lane == 0) {
+                        if (own[t]) a.Bi[it[t]] = wb[s0 + t];
+                        else { const double db = wb[s0 + t] - b[t]; if (db != 0.0) atomicAdd(ra.dB + it[t], db); }
+                    }
                 }
             }
         }
     }
+    if (ra.cnt_cur && lane < cnt && first == lane) ra.cnt_cur[x] = 0u;
     if (lane == 0) atomicAdd(a.out, half_sq);
 }
 

@@ -139,8 +139,10 @@ struct yue_ctx {
     DevBuf<int32_t> f_uq_items, f_loc_i, f_loc_j;
     DevBuf<float> f_wq, f_dQ;
     DevBuf<double> f_wp, f_wb, f_dP, f_dB;
+    DevBuf<unsigned> f_cnt;              // [2][n] users of a round touching an item (k_fism_round_lds)
     int64_t fn = 0;
     int fk = 0;
+    int opt_fism_inplace = 1;            // 0: every row a round's users touch goes through the difference buffers (round 3's form)
     int opt_fism_lds = 1;                // 0: yue_fism_rounds always through k_fism_round (working rows in global memory, item lists from the host)
     // exact path (chain_host.hip): touch keys / ordinals, runs, granule copies of the factor rows, control words
     DevBuf<uint32_t> ch_key, ch_val, ch_key2, ch_val2, ch_seg, ch_ord_i, ch_ord_j, ch_head, ch_incl, ch_ord_u, ch_rkey, ch_rval;
