@@ -459,6 +459,9 @@ def bench_fism(args, cp):
     negs = [negatives(e) for e in range(args.warmup + args.steps)]
     coef = np.array([pow(int(x) - 1, -alpha) if x > 1 else 0.0 for x in np.diff(ptr)], np.float64)
     dev = Device(cp.local_rank, raise_errors=True)
+    for kv in args.opt:
+        name, value = kv.split('=')
+        dev.set_option(name, int(value))
     dev.fism_set_model(P0, Q0, B0)
     for e in range(args.warmup):
         dev.fism_rounds(ptr, ev_i, negs[e], rho, coef, round_users, lr, reg, reg)
@@ -493,7 +496,7 @@ def bench_fism(args, cp):
                                '(upload of events and negatives) included in value' % (m, n, d, k, rho, alpha, lr, reg, round_users),
                    'final_half_sq_error': half,
                    'sequential_device_pass_draws_per_s': (nsl.stop - nsl.start) / seq_dt},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_fism_round_lds<KR=%d> (one wave per user, working rows in LDS: latency of the user\'s chain of draws)' % (1 if k <= 64 else 2 if k <= 128 else 4),
+        'roofline': {'bound': 'hbm', 'kernel': 'k_fism_round_lds<KR=%d> (one wave per user, working and round-start rows in LDS, rows of one user stored in place: the user\'s chain of draws, then the contended atomics of the shared rows)' % (1 if k <= 64 else 2 if k <= 128 else 4),
                      'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'algorithmic_bytes_per_draw': bytes_per_draw, 'traffic': None},
         'cpu_baseline': cpu}))
     dev.close()

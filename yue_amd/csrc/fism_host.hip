@@ -105,7 +105,7 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
         for (int64_t u = 0; u < m; ++u) { const int64_t nu = user_ptr[u + 1] - user_ptr[u]; if (nu > 1) cnt_max = std::max(cnt_max, nu + nu * rho); }
         for (int64_t u0 = 0; u0 < m; u0 += round_users) ev_max = std::max(ev_max, user_ptr[std::min(m, u0 + round_users)] - user_ptr[u0]);
         const size_t lds = (size_t)cnt_max * ((size_t)c->fk * 12 + 8);
-        if (c->opt_fism_lds && cnt_max >= 1 && cnt_max <= 64 && lds <= 64u * 1024u) {
+        if (c->opt_fism_lds && cnt_max >= 1 && cnt_max <= 64 && lds <= 160u * 1024u) {      // (gfx950: 160 KB of LDS per CU, all of it one workgroup's if asked for)
             const size_t nk = (size_t)c->fn * c->fk;
             HIPCHK(c->f_negs.resize((size_t)std::max<int64_t>(n_negs, 1))); HIPCHK(c->f_neg_ptr.resize((size_t)m + 1)); HIPCHK(c->f_coef.resize((size_t)m));
             HIPCHK(c->f_x.resize((size_t)ev_max * c->fk));
@@ -132,8 +132,23 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
                 cnt[0] = c->f_cnt.p; cnt[1] = c->f_cnt.p + c->fn;
                 hipLaunchKernelGGL(yue::k_fism_count_round, dim3((unsigned)std::min(m, round_users)), dim3(64), 0, c->stream, a, la.neg_ptr, (int64_t)0, std::min(m, round_users), cnt[0]);
             }
-            const void *kfn = kr_of(c->fk) == 1 ? (const void *)yue::k_fism_round_lds<1> : kr_of(c->fk) == 2 ? (const void *)yue::k_fism_round_lds<2> : (const void *)yue::k_fism_round_lds<4>;
-            HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef YUE_FISM_STAMPS
+            unsigned long long *d_stamps = nullptr;
+            HIPCHK(hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), c->stream));
+            la.stamps = d_stamps;
+#endif
+            // the round-start rows beside the working rows when both fit in the CU's LDS (a wave has the CU to itself anyway)
+            const size_t lds_rows = (lds + 7) & ~(size_t)7;
+            const bool start = 2 * lds_rows <= 160u * 1024u;
+            const size_t lds_launch = start ? 2 * lds_rows : lds;
+            const void *kfn = nullptr;
+            switch (kr_of(c->fk)) {
+                case 1: kfn = start ? (const void *)yue::k_fism_round_lds<1, true> : (const void *)yue::k_fism_round_lds<1, false>; break;
+                case 2: kfn = start ? (const void *)yue::k_fism_round_lds<2, true> : (const void *)yue::k_fism_round_lds<2, false>; break;
+                default: kfn = start ? (const void *)yue::k_fism_round_lds<4, true> : (const void *)yue::k_fism_round_lds<4, false>; break;
+            }
+            HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
             const dim3 apply_grid((unsigned)std::min<int64_t>(1024, (int64_t)(nk + 255) / 256));
             for (int64_t u0 = 0; u0 < m; u0 += round_users) {
                 const int64_t u1 = std::min(m, u0 + round_users);
@@ -142,11 +157,8 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
                 la.cnt_cur_r = la.cnt_cur = cnt[par]; la.cnt_next = cnt[par ^ 1];
                 la.next_begin = u1; la.next_end = std::min(m, u1 + round_users);
                 const dim3 grid((unsigned)(u1 - u0));
-                switch (kr_of(c->fk)) {
-                    case 1: hipLaunchKernelGGL(yue::k_fism_round_lds<1>, grid, dim3(64), lds, c->stream, a, la); break;
-                    case 2: hipLaunchKernelGGL(yue::k_fism_round_lds<2>, grid, dim3(64), lds, c->stream, a, la); break;
-                    default: hipLaunchKernelGGL(yue::k_fism_round_lds<4>, grid, dim3(64), lds, c->stream, a, la); break;
-                }
+                void *kargs[2] = {&a, &la};
+                HIPCHK(hipLaunchKernel(kfn, grid, dim3(64), kargs, lds_launch, c->stream));
                 hipLaunchKernelGGL(yue::k_fism_apply, apply_grid, dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->f_dP.p, c->f_dQ.p, c->f_dB.p, c->fn, c->fk);
             }
             hipLaunchKernelGGL(yue::k_fism_sumsq, dim3(256), dim3(256), 0, c->stream, c->fP.p, c->fQ.p, c->fBi.p, c->fn, c->fk, sc + 1);
@@ -154,6 +166,15 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
             double h[4];
             HIPCHK(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+#ifdef YUE_FISM_STAMPS
+            {
+                unsigned long long st[8];
+                HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost));
+                HIPCHK(hipFree(d_stamps));
+                const char *names[6] = {"count + find rows", "copy-in", "history sum", "draws", "item-history rows", "rows back / differences"};
+                for (int q = 0; q < 6; ++q) std::fprintf(stderr, "fism stamps: %-24s %8.2f us per wave\n", names[q], st[7] ? 0.01 * (double)st[q] / (double)st[7] : 0.0);
+            }
+#endif
             if (half_sq_out) *half_sq_out = h[0];
             if (sumsq3_out) { sumsq3_out[0] = h[1]; sumsq3_out[1] = h[2]; sumsq3_out[2] = h[3]; }
             return YUE_OK;

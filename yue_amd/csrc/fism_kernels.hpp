@@ -313,7 +313,15 @@ struct FismLdsArgs {
     const unsigned *cnt_cur_r;
     unsigned *cnt_cur, *cnt_next;
     int64_t next_begin, next_end;
+#ifdef YUE_FISM_STAMPS
+    unsigned long long *stamps;      // diagnostic build: [8] summed 100 MHz ticks per phase over all waves, [7] = waves
+#endif
 };
+#ifdef YUE_FISM_STAMPS
+#define FISM_STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) atomicAdd(ra.stamps + (slot), now_ - t_prev_); t_prev_ = now_; } while (0)
+#else
+#define FISM_STAMP(slot) do { } while (0)
+#endif
 
 // the distinct items user u touches (its events' items and its negatives), each counted once into cnt
 __device__ __forceinline__ void fism_count_rows(const FismArgs &a, const int64_t *neg_ptr, int64_t u, unsigned *cnt, int lane) {
@@ -333,39 +341,61 @@ __global__ void __launch_bounds__(64) k_fism_count_round(FismArgs a, const int64
     if (u < u_end) fism_count_rows(a, neg_ptr, u, cnt, threadIdx.x);
 }
 
-template <int KR>
+// START: the round-start rows stay in LDS beside the working rows (twice the LDS: the host asks for it when it fits), so that the
+// differences need no second read of the model.
+template <int KR, bool START>
 __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fism_lds[];
+    constexpr int kFismBatch = KR == 4 ? 16 : 32;        // rows whose loads are in flight together (a batch costs one memory latency)
     const int lane = threadIdx.x;
-    if (ra.cnt_next && ra.next_begin + blockIdx.x < ra.next_end) fism_count_rows(a, ra.neg_ptr, ra.next_begin + blockIdx.x, ra.cnt_next, lane);
-    const int64_t u = ra.u_begin + blockIdx.x;
-    if (u >= ra.u_end) return;
+#ifdef YUE_FISM_STAMPS
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    // this wave's user, and the user of the NEXT round whose rows it counts: both users' pointers, then both users' items, are
+    // asked for together (four dependent memory latencies in a row used to open every wave)
+    const int64_t u = ra.u_begin + blockIdx.x, un = ra.next_begin + blockIdx.x;
+    const bool has_me = u < ra.u_end, has_next = ra.cnt_next && un < ra.next_end;
     const int k = a.k;
-    const int64_t e0 = a.user_ptr[u], e1 = a.user_ptr[u + 1];
-    const int ne = (int)(e1 - e0);
-    if (ne <= 1) return;                                 // FISM.py:40-41
+    int64_t e0 = 0, e1 = 0, n0 = 0, f0 = 0, f1 = 0, g0 = 0;
+    if (has_me) { e0 = a.user_ptr[u]; e1 = a.user_ptr[u + 1]; n0 = ra.neg_ptr[u]; }
+    if (has_next) { f0 = a.user_ptr[un]; f1 = a.user_ptr[un + 1]; g0 = ra.neg_ptr[un]; }
+    const int ne = (int)(e1 - e0), nf = (int)(f1 - f0);
+    const int cnt = ne > 1 ? ne + ne * a.rho : 0;        // touches of this user (the host guarantees <= 64)
+    const int cntn = nf > 1 ? nf + nf * a.rho : 0;
+    const int32_t x = lane >= cnt ? -1 : lane < ne ? a.ev_i[e0 + lane] : a.negs[n0 + lane - ne];
+    const int32_t xn = lane >= cntn ? -1 : lane < nf ? a.ev_i[f0 + lane] : a.negs[g0 + lane - nf];
+    int first = lane;                                    // lowest lane holding the same item
+    bool firstn = lane < cntn;
+    for (int t = 0; t < (cnt > cntn ? cnt : cntn); ++t) {
+        const int32_t xt = __builtin_amdgcn_readlane(x, t), xnt = __builtin_amdgcn_readlane(xn, t);
+        if (lane < cnt && x == xt && t < first) first = t;
+        if (xn == xnt && t < lane) firstn = false;
+    }
+    // (here, not beside the differences at the end: measured 57 against 63 us per round -- the end of the wave is where the
+    // atomic units are busy)
+    if (firstn) atomicAdd(ra.cnt_next + xn, 1u);
+    if (!has_me || ne <= 1) return;                      // FISM.py:40-41
     double *wp = reinterpret_cast<double *>(fism_lds);                               // [rows_cap][k]
     double *wb = wp + (size_t)ra.rows_cap * k;                                       // [rows_cap]
     float *wq = reinterpret_cast<float *>(wb + ra.rows_cap);                         // [rows_cap][k]
+    double *sp = reinterpret_cast<double *>(wq + (size_t)ra.rows_cap * k + (((size_t)ra.rows_cap * k) & 1));   // START: the same three, as the round started
+    double *sb = sp + (size_t)ra.rows_cap * k;
+    float *sq = reinterpret_cast<float *>(sb + ra.rows_cap);
     const float regI32 = (float)a.regI;
-    const int cnt = ne + ne * a.rho;                     // touches of this user (the host guarantees <= 64)
-    const int64_t n0 = ra.neg_ptr[u];
-    const int32_t x = lane < ne ? a.ev_i[e0 + lane] : lane < cnt ? a.negs[n0 + lane - ne] : -1;
-    int first = lane;                                    // lowest lane holding the same item
-    for (int t = 0; t < cnt; ++t) { const int32_t xt = __builtin_amdgcn_readlane(x, t); if (lane < cnt && x == xt && t < first) first = t; }
     const unsigned long long fmask = __ballot(lane < cnt && first == lane);
     const int urow = __popcll(fmask & ((1ull << first) - 1ull));                    // the item's working row
     const int nuniq = __popcll(fmask);
     // rows of mine nobody else in the round touches
     const unsigned long long emask = __ballot(ra.cnt_cur_r && lane < cnt && first == lane && ra.cnt_cur_r[x] == 1u);
-    {   // copy in the rows this user touches, eight rows' loads in flight at a time
+    FISM_STAMP(0);                                        // counting the next round's rows, finding my own
+    {   // copy in the rows this user touches, a batch of rows' loads in flight at a time
         unsigned long long mleft = fmask;
-        for (int s0 = 0; s0 < nuniq; s0 += 8) {
-            int64_t it[8];
-            float q[8][KR];
-            double p[8][KR], b[8];
+        for (int s0 = 0; s0 < nuniq; s0 += kFismBatch) {
+            int64_t it[kFismBatch];
+            float q[kFismBatch][KR];
+            double p[kFismBatch][KR], b[kFismBatch];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < kFismBatch; ++t) {
                 const int src = mleft ? __ffsll((long long)mleft) - 1 : 0;
                 mleft &= mleft - 1;
                 it[t] = __builtin_amdgcn_readlane(x, src);
@@ -379,15 +409,22 @@ __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs r
                 b[t] = ex ? a.Bi[it[t]] : 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < kFismBatch; ++t) {
                 if (s0 + t < nuniq) {
 #pragma unroll
-                    for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) { wq[(s0 + t) * k + el] = q[t][r]; wp[(s0 + t) * k + el] = p[t][r]; } }
-                    if (lane == 0) wb[s0 + t] = b[t];
+                    for (int r = 0; r < KR; ++r) {
+                        const int el = 64 * r + lane;
+                        if (el < k) {
+                            wq[(s0 + t) * k + el] = q[t][r]; wp[(s0 + t) * k + el] = p[t][r];
+                            if (START) { sq[(s0 + t) * k + el] = q[t][r]; sp[(s0 + t) * k + el] = p[t][r]; }
+                        }
+                    }
+                    if (lane == 0) { wb[s0 + t] = b[t]; if (START) sb[s0 + t] = b[t]; }
                 }
             }
         }
     }
+    FISM_STAMP(1);                                        // copy-in
     double *xr = a.x_rows + (e0 - a.user_ptr[ra.u_begin]) * k;
     const double coef = a.coef[u];
     double hist[KR];
@@ -398,109 +435,161 @@ __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs r
 #pragma unroll
         for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) hist[r] = hist[r] + wp[s * k + el]; }
     }
+    FISM_STAMP(2);                                        // history sum
     double half_sq = 0.0;
     for (int e = 0; e < ne; ++e) {
+        // the event's own row stays in registers over its rho draws (round 4): between two draws of an event lies the sum and the
+        // update of the row, not also its trip to LDS and back; the bias likewise (every lane forms the same value)
         const int i = __builtin_amdgcn_readlane(urow, e);
-        double xs[KR];
+        double xs[KR], di[KR];
+        float qi[KR];
+        double bi = wb[i];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) xs[r] = 0.0;
+        for (int r = 0; r < KR; ++r) {
+            const int el = 64 * r + lane;
+            xs[r] = 0.0; di[r] = 0.0; qi[r] = 0.0f;
+            if (el < k) { di[r] = hist[r] - wp[i * k + el]; qi[r] = wq[i * k + el]; }
+        }
         for (int c = 0; c < a.rho; ++c) {
             const int j = __builtin_amdgcn_readlane(urow, ne + e * a.rho + c);
-            double di[KR], dj[KR];
-            float qi[KR], qj[KR];
+            double dj[KR];
+            float qj[KR], nj[KR];
             double ai = 0.0, aj = 0.0;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 const int el = 64 * r + lane;
-                di[r] = dj[r] = 0.0; qi[r] = qj[r] = 0.0f;
-                if (el < k) { di[r] = hist[r] - wp[i * k + el]; dj[r] = hist[r] - wp[j * k + el]; qi[r] = wq[i * k + el]; qj[r] = wq[j * k + el]; }
+                dj[r] = 0.0; qj[r] = 0.0f;
+                if (el < k) { dj[r] = hist[r] - wp[j * k + el]; qj[r] = wq[j * k + el]; }
                 const double m1 = di[r] * (double)qi[r]; ai = ai + m1;
                 const double m2 = dj[r] * (double)qj[r]; aj = aj + m2;
             }
-            const double bi = wb[i], bj = wb[j];
+            const double bj = wb[j];
             const double r_pos = coef * wave_sum_f64(ai) + bi;          // :54
             const double r_neg = coef * wave_sum_f64(aj) + bj;          // :55
             const double err = 1.0 - (r_pos - r_neg);
             half_sq = half_sq + 0.5 * (err * err);                      // :58
-            __builtin_amdgcn_wave_barrier();                            // (every lane has read the two biases)
-            if (lane == 0) {
-                wb[i] = bi + a.lr * (err - a.regB * bi);                // :59
-                wb[j] = bj - a.lr * (err + a.regB * bj);                // :60
-            }
+            const double bin = bi + a.lr * (err - a.regB * bi);         // :59
+            const double bjn = bj - a.lr * (err + a.regB * bj);         // :60
+            __builtin_amdgcn_wave_barrier();                            // (every lane has read the negative's bias)
+            if (lane == 0) wb[j] = bjn;
             const double ec = err * coef;
 #pragma unroll
             for (int r = 0; r < KR; ++r) {
                 const int el = 64 * r + lane;
                 const float ri = regI32 * qi[r], rj = regI32 * qj[r];
                 const float ni = (float)((double)qi[r] + a.lr * (ec * di[r] - (double)ri));     // :61
-                const float nj = (float)((double)qj[r] - a.lr * (ec * dj[r] + (double)rj));     // :62
-                const float dq = ni - nj;
+                nj[r] = (float)((double)qj[r] - a.lr * (ec * dj[r] + (double)rj));              // :62
+                const float dq = ni - nj[r];
                 xs[r] = xs[r] + err * (double)dq;                                                // :63
-                if (el < k) { wq[i * k + el] = ni; wq[j * k + el] = nj; }
+                qi[r] = ni;
+                if (el < k) wq[j * k + el] = nj[r];
+            }
+            bi = bin;
+            if (j == i) {                                               // (the reference never draws one of the user's own items; as the
+                bi = bjn;                                               // earlier forms: the negative's values are the ones that stay)
+#pragma unroll
+                for (int r = 0; r < KR; ++r) qi[r] = nj[r];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) xr[(int64_t)e * k + el] = xs[r]; }
+        for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; if (el < k) { wq[i * k + el] = qi[r]; xr[(int64_t)e * k + el] = xs[r]; } }
+        if (lane == 0) wb[i] = bi;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
+    FISM_STAMP(3);                                        // draws
     const double pc = 1.0 / (double)a.rho * coef;                       // :68, left to right
-    for (int e = 0; e < ne; ++e) {
-        const int s = __builtin_amdgcn_readlane(urow, e);
+    for (int eb = 0; eb < ne; eb += 8) {                                // (the x rows of eight events in flight at a time)
+        double xv[8][KR];
 #pragma unroll
-        for (int r = 0; r < KR; ++r) {
-            const int el = 64 * r + lane;
-            if (el < k) { const double p = wp[s * k + el]; wp[s * k + el] = p + a.lr * (pc * xr[(int64_t)e * k + el] - a.regI * p); }
-        }
-    }
-    {   // what this user changed: a row of its own goes back in place; of a shared row, working row - round-start row is added
-        // to the round's difference buffers (the round-start rows again eight at a time)
-        unsigned long long mleft = fmask;
-        for (int s0 = 0; s0 < nuniq; s0 += 8) {
-            int64_t it[8];
-            float q[8][KR];
-            double p[8][KR], b[8];
-            bool own[8];
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int src = mleft ? __ffsll((long long)mleft) - 1 : 0;
-                mleft &= mleft - 1;
-                it[t] = __builtin_amdgcn_readlane(x, src);
-                own[t] = (emask >> src) & 1ull;
-                const bool ex = s0 + t < nuniq && !own[t];
+            for (int r = 0; r < KR; ++r) { const int el = 64 * r + lane; xv[t][r] = (eb + t < ne && el < k) ? xr[(int64_t)(eb + t) * k + el] : 0.0; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (eb + t < ne) {
+                const int s = __builtin_amdgcn_readlane(urow, eb + t);
 #pragma unroll
                 for (int r = 0; r < KR; ++r) {
                     const int el = 64 * r + lane;
-                    q[t][r] = (ex && el < k) ? a.Q[it[t] * k + el] : 0.0f;
-                    p[t][r] = (ex && el < k) ? a.P[it[t] * k + el] : 0.0;
+                    if (el < k) { const double p = wp[s * k + el]; wp[s * k + el] = p + a.lr * (pc * xv[t][r] - a.regI * p); }
                 }
-                b[t] = ex ? a.Bi[it[t]] : 0.0;
+            }
+        }
+    }
+    FISM_STAMP(4);                                        // item-history rows
+    {   // what this user changed.  Shared rows first: working row - round-start row, formed IN the working rows (the round-start
+        // rows read again, a batch at a time; with START they are at hand) ...
+        unsigned long long mleft = fmask;
+        for (int s0 = 0; !START && s0 < nuniq; s0 += kFismBatch) {
+            float q[kFismBatch][KR];
+            double p[kFismBatch][KR], b[kFismBatch];
+            bool shared[kFismBatch];
+#pragma unroll
+            for (int t = 0; t < kFismBatch; ++t) {
+                const int src = mleft ? __ffsll((long long)mleft) - 1 : 0;
+                mleft &= mleft - 1;
+                const int64_t it = __builtin_amdgcn_readlane(x, src);
+                shared[t] = s0 + t < nuniq && !((emask >> src) & 1ull);
+#pragma unroll
+                for (int r = 0; r < KR; ++r) {
+                    const int el = 64 * r + lane;
+                    q[t][r] = (shared[t] && el < k) ? a.Q[it * k + el] : 0.0f;
+                    p[t][r] = (shared[t] && el < k) ? a.P[it * k + el] : 0.0;
+                }
+                b[t] = shared[t] ? a.Bi[it] : 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (s0 + t < nuniq) {
+            for (int t = 0; t < kFismBatch; ++t) {
+                if (shared[t]) {
 #pragma unroll
                     for (int r = 0; r < KR; ++r) {
                         const int el = 64 * r + lane;
-                        if (el < k) {
-                            if (own[t]) { a.Q[it[t] * k + el] = wq[(s0 + t) * k + el]; a.P[it[t] * k + el] = wp[(s0 + t) * k + el]; }
-                            else {
-                                const float dq = wq[(s0 + t) * k + el] - q[t][r];
-                                if (dq != 0.0f) atomicAdd(ra.dQ + it[t] * k + el, dq);
-                                const double dp = wp[(s0 + t) * k + el] - p[t][r];
-                                if (dp != 0.0) atomicAdd(ra.dP + it[t] * k + el, dp);
-                            }
-                        }
+                        if (el < k) { wq[(s0 + t) * k + el] = wq[(s0 + t) * k + el] - q[t][r]; wp[(s0 + t) * k + el] = wp[(s0 + t) * k + el] - p[t][r]; }
                     }
-                    if (lane == 0) {
-                        if (own[t]) a.Bi[it[t]] = wb[s0 + t];
-                        else { const double db = wb[s0 + t] - b[t]; if (db != 0.0) atomicAdd(ra.dB + it[t], db); }
+                    if (lane == 0) wb[s0 + t] = wb[s0 + t] - b[t];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ... then every row on its way with nothing left to wait for: a row of the user's own back in place, a shared row's
+        // differences into the round's buffers (no-return atomics; on this target they count on the same counter as loads, and a
+        // batch of loads behind them would wait for every one of them to land)
+        mleft = fmask;
+        for (int s = 0; s < nuniq; ++s) {
+            const int src = __ffsll((long long)mleft) - 1;
+            mleft &= mleft - 1;
+            const int64_t it = __builtin_amdgcn_readlane(x, src);
+            const bool own = (emask >> src) & 1ull;
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const int el = 64 * r + lane;
+                if (el < k) {
+                    float vq = wq[s * k + el];
+                    double vp = wp[s * k + el];
+                    if (own) { a.Q[it * k + el] = vq; a.P[it * k + el] = vp; }
+                    else {
+                        if (START) { vq = vq - sq[s * k + el]; vp = vp - sp[s * k + el]; }
+                        if (vq != 0.0f) atomicAdd(ra.dQ + it * k + el, vq);
+                        if (vp != 0.0) atomicAdd(ra.dP + it * k + el, vp);
                     }
                 }
+            }
+            if (lane == 0) {
+                double vb = wb[s];
+                if (own) a.Bi[it] = vb;
+                else { if (START) vb = vb - sb[s]; if (vb != 0.0) atomicAdd(ra.dB + it, vb); }
             }
         }
     }
     if (ra.cnt_cur && lane < cnt && first == lane) ra.cnt_cur[x] = 0u;
+    FISM_STAMP(5);                                        // rows back in place / differences
+#ifdef YUE_FISM_STAMPS
+    if (lane == 0) atomicAdd(ra.stamps + 7, 1ull);
+#endif
     if (lane == 0) atomicAdd(a.out, half_sq);
 }
 
