@@ -180,7 +180,9 @@ def test_rounds_with_working_rows_in_lds_equal_the_global_form(dev, k):
     # users of at most 64 touches take k_fism_round_lds (the wave finds its rows itself, working copies in LDS): same pass as
     # k_fism_round (option fism_lds = 0) and as the NumPy oracle; ragged users, duplicates inside a user, repeated negatives;
     # with and without the rows only one user of a round touches stored in place (option fism_inplace: one user per round =
-    # every row in place, 5 = some of them, 100 = the users of the whole problem share most rows)
+    # every row in place, 5 = some of them, 100 = the users of the whole problem share most rows).  k = 64 and 10: the round-start
+    # rows stay in LDS beside the working rows (k_fism_round_lds<KR, true>); k = 130: 100 KB of working rows, twice that does not
+    # fit in 160 KB -> <4, false>, the model rows are read again for the differences
     from oracle.numpy_fism import fism_rounds
     rng = np.random.RandomState(11 + k)
     n, rho, alpha = 50, 3, 0.5
