@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64) k_fism_count_round(FismArgs a, const int64
 template <int KR, bool START>
 __global__ void __launch_bounds__(64) k_fism_round_lds(FismArgs a, FismLdsArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fism_lds[];
-    constexpr int kFismBatch = KR == 4 ? 16 : 32;        // rows whose loads are in flight together (a batch costs one memory latency)
+    constexpr int kFismBatch = 64 / KR;                 // rows whose loads are in flight together (a batch costs one memory latency)
     const int lane = threadIdx.x;
 #ifdef YUE_FISM_STAMPS
     unsigned long long t_prev_ = __builtin_amdgcn_s_memrealtime();
