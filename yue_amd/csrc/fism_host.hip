@@ -139,8 +139,12 @@ int yue_fism_rounds(yue_ctx *c, const int64_t *user_ptr, int64_t m, const int32_
             la.stamps = d_stamps;
 #endif
             // the round-start rows beside the working rows when both fit in the CU's LDS (a wave has the CU to itself anyway)
+            // -- as long as that leaves the round's waves resident at once: a round larger than the CUs can hold with the doubled
+            // LDS runs in generations (rounds of 512 users at 93 KB: one workgroup per CU, 130 against 68 us per round of 256)
             const size_t lds_rows = (lds + 7) & ~(size_t)7;
-            const bool start = 2 * lds_rows <= 160u * 1024u;
+            int cus = 0;
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            const bool start = 2 * lds_rows <= 160u * 1024u && std::min(m, round_users) <= (int64_t)cus * (int64_t)((160u * 1024u) / (2 * lds_rows));
             const size_t lds_launch = start ? 2 * lds_rows : lds;
             const void *kfn = nullptr;
             switch (kr_of(c->fk)) {
