@@ -212,3 +212,47 @@ def test_rounds_with_working_rows_in_lds_equal_the_global_form(dev, k):
         half_o = fism_rounds(Po, Qo, Bo, ptr, ev_i, negs, rho, alpha, 0.02, 0.01, 0.03, round_users)
         for half, P, Q, Bi in res:
             assert rel_err(P, Po) < 1e-6 and rel_err(Bi, Bo) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(half - half_o) < 1e-6 * half_o, round_users
+
+
+@pytest.mark.parametrize('k,round_users', [(64, 96), (32, 250), (130, 40)])
+def test_many_rounds_with_popular_items_match_the_numpy_oracle(dev, k, round_users):
+    # 1,500 ragged users on 300 items with a popular head over many rounds (a last round shorter than the others): rows in
+    # place, contended differences and the count arrays that swap from round to round, against the NumPy oracle of the round form;
+    # and the forms of the device path (rows in place or not, working rows in LDS or global memory) against each other
+    from oracle.numpy_fism import fism_rounds
+    rng = np.random.RandomState(500 + k)
+    m, n, rho, alpha = 1500, 300, 2, 0.5
+    sizes = rng.randint(0, 13, m)
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    pop = 1.0 / np.arange(1, n + 1) ** 0.8
+    pop /= pop.sum()
+    ev_i = rng.choice(n, size=int(ptr[-1]), p=pop).astype(np.int32)
+    negs = []
+    for u in range(m):
+        if sizes[u] > 1:
+            mine = ev_i[ptr[u]:ptr[u + 1]]
+            d = rng.randint(0, n, sizes[u] * rho)
+            while True:
+                bad = np.isin(d, mine)
+                if not bad.any():
+                    break
+                d[bad] = rng.randint(0, n, int(bad.sum()))
+            negs.append(d)
+    negs = np.concatenate(negs).astype(np.int32)
+    P0, Q0, B0 = rng.rand(n, k) / 100, (rng.rand(n, k) / 10).astype(np.float32), rng.rand(n) / 100
+    lr, reg_i, reg_b = 0.002, 0.01, 0.01
+    Po, Qo, Bo = P0.copy(), Q0.copy(), B0.copy()
+    half_o = fism_rounds(Po, Qo, Bo, ptr, ev_i, negs, rho, alpha, lr, reg_i, reg_b, round_users)
+    assert np.isfinite(half_o)
+    try:
+        for lds, inplace in ((1, 1), (1, 0), (0, 1)):
+            dev.set_option('fism_lds', lds)
+            dev.set_option('fism_inplace', inplace)
+            dev.fism_set_model(P0, Q0, B0)
+            half, _, _, _ = dev.fism_rounds(ptr, ev_i, negs, rho, coefs(ptr, alpha), round_users, lr, reg_i, reg_b)
+            P, Q, Bi = np.empty_like(P0), np.empty_like(Q0), np.empty_like(B0)
+            dev.fism_get_model(P, Q, Bi)
+            assert rel_err(P, Po) < 1e-6 and rel_err(Bi, Bo) < 1e-6 and rel_err(Q, Qo) < 1e-6 and abs(half - half_o) < 1e-6 * half_o, (lds, inplace)
+    finally:
+        dev.set_option('fism_lds', 1)
+        dev.set_option('fism_inplace', 1)
